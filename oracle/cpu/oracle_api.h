@@ -1,0 +1,42 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  Parity unpinned (see oracle/README.md).
+ * C entry points of the CPU restatement, loaded with ctypes by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg.  Nothing under delta_graph_slam_amd/ may include or load this. */
+#ifndef ORACLE_API_H
+#define ORACLE_API_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ndt_params {
+  double resolution, step_size, outlier_ratio, transformation_epsilon, min_covar_eigvalue_mult;
+  int32_t max_iterations, search_method, min_points_per_voxel, line_search, mt_max_step_iterations, num_threads, fix_hessian_d1;
+} orc_ndt_params;
+
+typedef struct orc_result {
+  float T[16];
+  int32_t converged, iterations, evaluations, pad;
+  double score;
+} orc_result;
+
+void orc_ndt_default_params(orc_ndt_params* p);
+void* orc_ndt_create(const orc_ndt_params* p);
+void orc_ndt_destroy(void* h);
+void orc_ndt_set_target(void* h, const float* xyz16, int64_t n);
+void orc_ndt_set_source(void* h, const float* xyz16, int64_t n);
+void orc_ndt_align(void* h, const float* guess16, orc_result* out, double* trajectory, int32_t* traj_len);
+double orc_ndt_derivatives(void* h, const double* p6, const float* T16_or_null, double* g6, double* H36, int32_t compute_hessian);
+/* voxel table dump: returns number of leaves; arrays sized by a first call with null pointers */
+int64_t orc_ndt_voxels(void* h, int64_t* keys, int32_t* counts, int32_t* valid, double* mean3, double* cov9, double* icov9);
+void orc_ndt_grid(void* h, int32_t* min_b3, int32_t* max_b3, int32_t* div_b3);
+void orc_euler_angles_012(const float* T16, float* out3);
+void orc_pose_to_matrix_f32(const double* p6, float* T16);
+void orc_svd_solve6(const double* A36, const double* b6, double* x6);
+void orc_ldlt_solve6(const double* A36, const double* b6, double* x6);
+void orc_sym_eig3(const double* A9, double* evals3, double* V9);
+int32_t orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

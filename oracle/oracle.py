@@ -1,0 +1,220 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  **Parity unpinned.**
+
+ctypes front-end of the CPU restatement (oracle/cpu/*.cpp -> oracle/_build/liboracle.so).
+
+Why "unpinned": the arithmetic of the hot path lives in koide3/ndt_omp, SMRT-AIST/fast_gicp and PCL, which
+the reference clones at un-pinned HEAD (/root/reference/README.md:21-22, docker/noetic/Dockerfile:14-15) and
+which are absent from this image; the reference ships no tests, fixtures or golden vectors (SURVEY.md §4,
+§8c).  The restatement follows the published algorithms (Magnusson 2009 ch. 6; More & Thuente 1994;
+Segal et al. 2009 "Generalized-ICP"; fast_gicp's LM driver as recalled in SURVEY.md App. A/B) and is
+anchored on the reference's own call sites (registrations.cpp:22-124, scan_matching_odometry_nodelet.cpp:
+173-270, loop_detector.hpp:119-173, information_matrix_calculator.cpp:77-108) plus analytic known-answer
+tests in tests/ (finite differences, scipy cKDTree, numpy.linalg).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C++ restatement with g++ (see oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class NdtParams(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("step_size", C.c_double), ("outlier_ratio", C.c_double),
+                ("transformation_epsilon", C.c_double), ("min_covar_eigvalue_mult", C.c_double),
+                ("max_iterations", C.c_int32), ("search_method", C.c_int32), ("min_points_per_voxel", C.c_int32),
+                ("line_search", C.c_int32), ("mt_max_step_iterations", C.c_int32), ("num_threads", C.c_int32),
+                ("fix_hessian_d1", C.c_int32)]
+
+
+class GicpParams(C.Structure):
+    _fields_ = [("transformation_epsilon", C.c_double), ("rotation_epsilon", C.c_double),
+                ("max_correspondence_distance", C.c_double), ("lm_init_lambda_factor", C.c_double),
+                ("max_iterations", C.c_int32), ("k_correspondences", C.c_int32), ("regularization", C.c_int32),
+                ("optimizer", C.c_int32), ("lm_max_iterations", C.c_int32), ("num_threads", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("converged", C.c_int32), ("iterations", C.c_int32),
+                ("evaluations", C.c_int32), ("pad", C.c_int32), ("score", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_ndt_create.restype = C.c_void_p
+        _lib.orc_ndt_derivatives.restype = C.c_double
+        _lib.orc_ndt_voxels.restype = C.c_int64
+        if hasattr(_lib, "orc_gicp_create"):
+            _lib.orc_gicp_create.restype = C.c_void_p
+            _lib.orc_fitness_score.restype = C.c_double
+            _lib.orc_gicp_linearize.restype = C.c_double
+            _lib.orc_gicp_compute_error.restype = C.c_double
+    return _lib
+
+
+SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
+
+
+def _f32c(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f64c(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _colmajor16(T) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T.reshape(16))
+
+
+def _from_colmajor16(t16) -> np.ndarray:
+    return np.array(t16, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class NdtOracle:
+    """CPU restatement of pclomp::NormalDistributionsTransform (registrations.cpp:101-120)."""
+
+    def __init__(self, resolution=1.0, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
+                 step_size=0.1, outlier_ratio=0.55, line_search=0, num_threads=0, min_points_per_voxel=6,
+                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0):
+        L = lib()
+        p = NdtParams()
+        L.orc_ndt_default_params(C.byref(p))
+        p.resolution = resolution
+        p.transformation_epsilon = transformation_epsilon
+        p.max_iterations = max_iterations
+        p.search_method = SEARCH[search_method] if isinstance(search_method, str) else int(search_method)
+        p.step_size = step_size
+        p.outlier_ratio = outlier_ratio
+        p.line_search = line_search
+        p.num_threads = num_threads
+        p.min_points_per_voxel = min_points_per_voxel
+        p.min_covar_eigvalue_mult = min_covar_eigvalue_mult
+        p.mt_max_step_iterations = mt_max_step_iterations
+        p.fix_hessian_d1 = fix_hessian_d1
+        self.params = p
+        self.max_iterations = max_iterations
+        self._h = C.c_void_p(L.orc_ndt_create(C.byref(p)))
+
+    def __del__(self):
+        try:
+            lib().orc_ndt_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_target(self, cloud):
+        a, pa = _f32c(cloud)
+        assert a.ndim == 2 and a.shape[1] == 4
+        lib().orc_ndt_set_target(self._h, pa, C.c_int64(a.shape[0]))
+
+    def set_source(self, cloud):
+        a, pa = _f32c(cloud)
+        assert a.ndim == 2 and a.shape[1] == 4
+        lib().orc_ndt_set_source(self._h, pa, C.c_int64(a.shape[0]))
+
+    def align(self, guess=None):
+        g = _colmajor16(np.eye(4) if guess is None else guess)
+        res = Result()
+        traj = np.zeros((self.max_iterations + 4, 6))
+        tl = C.c_int32(0)
+        lib().orc_ndt_align(self._h, g.ctypes.data_as(C.POINTER(C.c_float)), C.byref(res),
+                            traj.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tl))
+        return dict(T=_from_colmajor16(res.T), converged=bool(res.converged), iterations=res.iterations,
+                    evaluations=res.evaluations, score=res.score, trajectory=traj[:tl.value].copy())
+
+    def derivatives(self, p, T=None, compute_hessian=True):
+        p, pp = _f64c(p)
+        g = np.zeros(6)
+        H = np.zeros((6, 6))
+        Tp = None
+        if T is not None:
+            t16 = _colmajor16(T)
+            Tp = t16.ctypes.data_as(C.POINTER(C.c_float))
+        s = lib().orc_ndt_derivatives(self._h, pp, Tp, g.ctypes.data_as(C.POINTER(C.c_double)),
+                                      H.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(1 if compute_hessian else 0))
+        return s, g, H
+
+    def voxels(self):
+        L = lib()
+        n = L.orc_ndt_voxels(self._h, None, None, None, None, None, None)
+        keys = np.zeros(n, np.int64)
+        counts = np.zeros(n, np.int32)
+        valid = np.zeros(n, np.int32)
+        mean = np.zeros((n, 3))
+        cov = np.zeros((n, 3, 3))
+        icov = np.zeros((n, 3, 3))
+        L.orc_ndt_voxels(self._h, keys.ctypes.data_as(C.POINTER(C.c_int64)), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                         valid.ctypes.data_as(C.POINTER(C.c_int32)), mean.ctypes.data_as(C.POINTER(C.c_double)),
+                         cov.ctypes.data_as(C.POINTER(C.c_double)), icov.ctypes.data_as(C.POINTER(C.c_double)))
+        o = np.argsort(keys)
+        return dict(keys=keys[o], counts=counts[o], valid=valid[o].astype(bool), mean=mean[o], cov=cov[o], icov=icov[o])
+
+    def grid(self):
+        mn = (C.c_int32 * 3)()
+        mx = (C.c_int32 * 3)()
+        dv = (C.c_int32 * 3)()
+        lib().orc_ndt_grid(self._h, mn, mx, dv)
+        return np.array(mn), np.array(mx), np.array(dv)
+
+
+def euler_angles_012(T) -> np.ndarray:
+    out = np.zeros(3, np.float32)
+    t16 = _colmajor16(T)
+    lib().orc_euler_angles_012(t16.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def pose_to_matrix_f32(p) -> np.ndarray:
+    p, pp = _f64c(p)
+    out = np.zeros(16, np.float32)
+    lib().orc_pose_to_matrix_f32(pp, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return _from_colmajor16(out)
+
+
+def svd_solve6(A, b):
+    A, pa = _f64c(A)
+    b, pb = _f64c(b)
+    x = np.zeros(6)
+    lib().orc_svd_solve6(pa, pb, x.ctypes.data_as(C.POINTER(C.c_double)))
+    return x
+
+
+def ldlt_solve6(A, b):
+    A, pa = _f64c(A)
+    b, pb = _f64c(b)
+    x = np.zeros(6)
+    lib().orc_ldlt_solve6(pa, pb, x.ctypes.data_as(C.POINTER(C.c_double)))
+    return x
+
+
+def sym_eig3(A):
+    A, pa = _f64c(A)
+    ev = np.zeros(3)
+    V = np.zeros((3, 3))
+    lib().orc_sym_eig3(pa, ev.ctypes.data_as(C.POINTER(C.c_double)), V.ctypes.data_as(C.POINTER(C.c_double)))
+    return ev, V
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
