@@ -1,0 +1,89 @@
+"""ctypes binding of libdgs_reg.so (include/dgs_reg.h).  Fails loudly when the HIP library is missing --
+there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgs_reg.so")
+
+DGS_OK = 0
+STATUS = {0: "DGS_OK", 1: "DGS_ERR_INVALID_ARGUMENT", 2: "DGS_ERR_HIP", 3: "DGS_ERR_NO_TARGET", 4: "DGS_ERR_NO_SOURCE",
+          5: "DGS_ERR_GRID_TOO_LARGE", 6: "DGS_ERR_UNSUPPORTED"}
+METHOD_NDT, METHOD_GICP = 0, 1
+NDT_SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
+GICP_REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
+K_NDT_DERIVATIVES, K_NDT_SOLVE, K_NDT_VOXEL_BUILD, K_NN_SEARCH, K_GICP_LINEARIZE, K_GICP_COVARIANCE, K_TRANSFORM = range(7)
+
+
+class DgsError(RuntimeError):
+    def __init__(self, status: int, msg: str = ""):
+        self.status = status
+        super().__init__(f"{STATUS.get(status, status)}: {msg}")
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("method", C.c_int32), ("device", C.c_int32), ("num_threads", C.c_int32),
+        ("transformation_epsilon", C.c_double), ("maximum_iterations", C.c_int32), ("ndt_search_method", C.c_int32),
+        ("ndt_resolution", C.c_double), ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double),
+        ("ndt_min_covar_eigvalue_mult", C.c_double), ("ndt_min_points_per_voxel", C.c_int32),
+        ("ndt_line_search", C.c_int32), ("ndt_mt_max_step_iterations", C.c_int32), ("ndt_fix_hessian_d1", C.c_int32),
+        ("gicp_max_correspondence_distance", C.c_double), ("gicp_rotation_epsilon", C.c_double),
+        ("gicp_lm_init_lambda_factor", C.c_double), ("gicp_correspondence_randomness", C.c_int32),
+        ("gicp_regularization", C.c_int32), ("gicp_optimizer", C.c_int32), ("gicp_lm_max_iterations", C.c_int32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [("final_transformation", C.c_float * 16), ("converged", C.c_int32), ("iterations", C.c_int32),
+                ("evaluations", C.c_int32), ("status", C.c_int32), ("score", C.c_double), ("fitness", C.c_double)]
+
+
+# every symbol include/dgs_reg.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "dgs_params_init", "dgs_create", "dgs_destroy", "dgs_last_error", "dgs_abi_version", "dgs_set_stream",
+    "dgs_synchronize", "dgs_set_input_target", "dgs_set_input_source", "dgs_align", "dgs_get_fitness_score",
+    "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_align_batch", "dgs_profile_enable",
+    "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_get_voxels",
+]
+
+_lib = None
+
+
+def load():
+    """Load libdgs_reg.so.  Raises ImportError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C delta_graph_slam_amd/csrc).  delta_graph_slam_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    lib.dgs_last_error.restype = C.c_char_p
+    lib.dgs_last_error.argtypes = [C.c_void_p]
+    lib.dgs_params_init.argtypes = [P(Params), C.c_int32]
+    lib.dgs_create.argtypes = [P(Params), P(C.c_void_p)]
+    lib.dgs_destroy.argtypes = [C.c_void_p]
+    lib.dgs_destroy.restype = None
+    lib.dgs_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dgs_synchronize.argtypes = [C.c_void_p]
+    lib.dgs_set_input_target.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    lib.dgs_set_input_source.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    lib.dgs_align.argtypes = [C.c_void_p, C.c_void_p, P(Result), C.c_void_p, C.c_int32]
+    lib.dgs_get_fitness_score.argtypes = [C.c_void_p, C.c_double, P(C.c_double)]
+    lib.dgs_get_inlier_fraction.argtypes = [C.c_void_p, C.c_double, P(C.c_double)]
+    lib.dgs_nearest_search_target.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dgs_align_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                    C.c_double, P(Result)]
+    lib.dgs_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+    lib.dgs_profile_get.argtypes = [C.c_void_p, C.c_int32, P(C.c_double), P(C.c_int64)]
+    lib.dgs_profile_reset.argtypes = [C.c_void_p]
+    lib.dgs_get_counts.argtypes = [C.c_void_p, P(C.c_int64)]
+    lib.dgs_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_double), C.c_void_p, C.c_void_p]
+    lib.dgs_ndt_get_voxels.argtypes = [C.c_void_p, P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib

@@ -1,0 +1,146 @@
+// Shared host/device definitions of libdgs_reg.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/dgs_reg.h"
+
+namespace dgs {
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kBlock = 256;        // 4 waves per workgroup: one wave per SIMD
+constexpr int kAccum = 28;         // score + 6 gradient + 21 upper-triangle Hessian terms
+constexpr int kAccumPad = 32;      // partial-sum row stride (doubles)
+constexpr int kMaxPartialBlocks = 1024;  // per pair
+
+// ---- NDT voxel-Gaussian target model in HBM ------------------------------------------------------------
+// One 48-byte record per occupied voxel (three 16-byte loads): the mean stays double because upstream forms
+// q = float(double(x') - mean), the inverse covariance is what upstream casts to float.
+struct __attribute__((aligned(16))) VoxelRec {
+  double mean[3];
+  float icov[6];  // xx, xy, xz, yy, yz, zz
+};
+static_assert(sizeof(VoxelRec) == 48, "VoxelRec must be 48 bytes");
+
+struct VoxelGrid {
+  int min_b[3];
+  int max_b[3];
+  int div_b[3];
+  int mul1, mul2;        // divb_mul = (1, div0, div0*div1)
+  float leaf;            // leaf_size (all axes equal: setResolution)
+  float inv_leaf;        // 1 / leaf_size as float (VoxelGridCovariance::inverse_leaf_size_)
+  const int* cell2vox;   // dense [div0*div1*div2] -> voxel id or -1
+  const VoxelRec* vox;   // [n_occupied]
+  const float4* centroid;  // float centroid + (w = 1 valid / 0 invalid), KDTREE mode
+};
+
+// ---- per-pair NDT optimiser state (device resident; written by the init / solve kernels) ---------------
+enum NdtPhase : int {
+  PH_INIT_EVAL = 0,   // waiting for derivatives at the initial guess
+  PH_MT_FIRST = 1,    // waiting for full derivatives at the first trial step of this iteration
+  PH_MT_TRIAL = 2,    // waiting for score + gradient at a More-Thuente trial step
+  PH_MT_HESSIAN = 3,  // waiting for the Hessian at the accepted step
+  PH_PROBE = 4,       // test hook: reduce only
+  PH_DONE = 5
+};
+
+struct NdtPair {
+  // -- read by the derivative kernel
+  float T[12];         // row-major 3x4 float transform of this evaluation
+  float jang[8][3];    // eq. 6.19 tables (float, from double trig)
+  float hang[15][3];   // eq. 6.21 tables
+  int need_hessian;
+  int active;          // 0: every kernel returns immediately for this pair
+  // -- optimiser state (solve kernel, lane 0)
+  int phase;
+  int nr_iterations;
+  int evaluations;
+  int converged;
+  int step_iterations;
+  int interval_converged;
+  int open_interval;
+  int pad0;
+  double p[6];         // current pose (x, y, z, rx, ry, rz)
+  double x_t[6];       // pose of the evaluation in flight
+  double dir[6];       // unit Newton direction (possibly reversed)
+  double score;        // last evaluated score / gradient / Hessian
+  double grad[6];
+  double hess[36];
+  double phi_0, d_phi_0;
+  double a_t, a_l, f_l, g_l, a_u, f_u, g_u;
+  double step_init;
+  float final_T[16];   // column-major, = final_transformation_
+};
+
+struct NdtConsts {
+  double gauss_d1, gauss_d2;
+  double step_size, trans_eps;
+  int max_iterations, line_search, mt_max_step_iterations, fix_hessian_d1;
+  int search_method;
+};
+
+struct NdtInit {  // host -> device per pair, per align
+  float guess[16];  // column-major
+  double p0[6];
+};
+
+// ---- error handling --------------------------------------------------------------------------------------
+#define DGS_HIP_TRY(h, expr)                                                                      \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                               \
+      return DGS_ERR_HIP;                                                                         \
+    }                                                                                             \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* ptr = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+// ---- device helpers --------------------------------------------------------------------------------------
+// Individually rounded float ops.  hipcc contracts a*b+c into FMA by default (-ffp-contract=fast-honor-pragmas) and
+// HIP's __fmul_rn/__fadd_rn are plain operators, so the pragma is what keeps these two roundings apart.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+// pcl::transformPointCloud row in float: ((m0 x + m1 y) + m2 z) + m3, every step rounded
+__device__ __forceinline__ float affine_row_rn(float m0, float m1, float m2, float m3, float x, float y, float z) {
+  return add_rn(add_rn(add_rn(mul_rn(m0, x), mul_rn(m1, y)), mul_rn(m2, z)), m3);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+}  // namespace dgs

@@ -1,0 +1,486 @@
+// C ABI of libdgs_reg.so (include/dgs_reg.h).  Thin: argument checks, device/stream plumbing, uploads, and
+// dispatch into the kernels' host drivers.  No exception ever crosses this boundary.
+#include <cfloat>
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <new>
+
+#include "handle.h"
+
+using namespace dgs;
+
+namespace dgs {
+
+int ensure_pinned(dgs_handle* h, size_t bytes) {
+  if (bytes <= h->pinned_bytes) return DGS_OK;
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  h->pinned = nullptr;
+  h->pinned_bytes = 0;
+  const size_t want = std::max<size_t>(bytes * 2, 1 << 16);
+  hipError_t e = hipHostMalloc(&h->pinned, want, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    h->err = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+    return DGS_ERR_HIP;
+  }
+  h->pinned_bytes = want;
+  return DGS_OK;
+}
+
+int prof_begin(dgs_handle* h, int kernel_id) {
+  Profiler& p = h->prof;
+  if (!p.enabled) return -1;
+  if (p.next_free == p.pool.size()) {
+    EventPair ep;
+    if (hipEventCreate(&ep.start) != hipSuccess || hipEventCreate(&ep.stop) != hipSuccess) return -1;
+    p.pool.push_back(ep);
+  }
+  const int slot = (int)p.next_free++;
+  (void)hipEventRecord(p.pool[slot].start, h->stream);
+  (void)kernel_id;
+  return slot;
+}
+
+void prof_end(dgs_handle* h, int kernel_id, int slot) {
+  if (slot < 0) return;
+  Profiler& p = h->prof;
+  (void)hipEventRecord(p.pool[slot].stop, h->stream);
+  p.pending[kernel_id].push_back(slot);
+}
+
+static void prof_collect(dgs_handle* h) {
+  Profiler& p = h->prof;
+  (void)hipStreamSynchronize(h->stream);
+  for (int k = 0; k < DGS_K_COUNT; k++) {
+    for (int slot : p.pending[k]) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.pool[slot].start, p.pool[slot].stop) == hipSuccess) {
+        p.total_ms[k] += ms;
+        p.launches[k] += 1;
+      }
+    }
+    p.pending[k].clear();
+  }
+  p.next_free = 0;
+}
+
+// out = T * in  (K8 transform_cloud; pcl::transformPointCloud semantics, pad lane set to 1)
+__global__ __launch_bounds__(kBlock) void transform_kernel(const float4* __restrict__ in, float4* __restrict__ out, int64_t n, float t0, float t1,
+                                                           float t2, float t3, float t4, float t5, float t6, float t7, float t8, float t9,
+                                                           float t10, float t11) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 x = in[i];
+  float4 y;
+  y.x = t0 * x.x + t1 * x.y + t2 * x.z + t3;
+  y.y = t4 * x.x + t5 * x.y + t6 * x.z + t7;
+  y.z = t8 * x.x + t9 * x.y + t10 * x.z + t11;
+  y.w = 1.f;
+  out[i] = y;
+}
+
+int transform_cloud(dgs_handle* h, const float4* in, float4* out, int64_t n, const float* T) {
+  if (n == 0) return DGS_OK;
+  int slot = prof_begin(h, DGS_K_TRANSFORM);
+  hipLaunchKernelGGL(transform_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, in, out, n, T[0], T[4], T[8], T[12],
+                     T[1], T[5], T[9], T[13], T[2], T[6], T[10], T[14]);
+  prof_end(h, DGS_K_TRANSFORM, slot);
+  return DGS_OK;
+}
+
+}  // namespace dgs
+
+static int set_device(dgs_handle* h) {
+  DGS_HIP_TRY(h, hipSetDevice(h->device));
+  return DGS_OK;
+}
+
+static int upload_cloud(dgs_handle* h, DevBuf<float4>& buf, const float* xyz16, int64_t n, int on_device) {
+  if (n == 0) return DGS_OK;
+  DGS_HIP_TRY(h, buf.reserve((size_t)n));
+  DGS_HIP_TRY(h, hipMemcpyAsync(buf.ptr, xyz16, (size_t)n * sizeof(float4), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  if (!on_device) DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));  // the host pointer is not retained past return
+  return DGS_OK;
+}
+
+static thread_local std::string g_create_error;  // dgs_last_error(NULL): why the last dgs_create on this thread failed
+
+extern "C" {
+
+int dgs_abi_version(void) { return DGS_ABI_VERSION; }
+
+int dgs_params_init(dgs_params* p, int32_t method) {
+  if (!p) return DGS_ERR_INVALID_ARGUMENT;
+  std::memset(p, 0, sizeof(*p));
+  p->struct_size = sizeof(dgs_params);
+  p->method = method;
+  p->device = -1;
+  p->num_threads = 0;
+  p->transformation_epsilon = 0.01;
+  p->maximum_iterations = 64;
+  p->ndt_search_method = DGS_NDT_DIRECT7;
+  p->ndt_resolution = 0.5;
+  p->ndt_step_size = 0.1;
+  p->ndt_outlier_ratio = 0.55;
+  p->ndt_min_covar_eigvalue_mult = 0.01;
+  p->ndt_min_points_per_voxel = 6;
+  p->ndt_line_search = DGS_NDT_LS_MORE_THUENTE;
+  p->ndt_mt_max_step_iterations = 10;
+  p->ndt_fix_hessian_d1 = 0;
+  p->gicp_max_correspondence_distance = 2.5;
+  p->gicp_rotation_epsilon = 2e-3;
+  p->gicp_lm_init_lambda_factor = 1e-9;
+  p->gicp_correspondence_randomness = 20;
+  p->gicp_regularization = DGS_GICP_REG_PLANE;
+  p->gicp_optimizer = DGS_GICP_OPT_LEVENBERG_MARQUARDT;
+  p->gicp_lm_max_iterations = 10;
+  if (method != DGS_METHOD_NDT && method != DGS_METHOD_GICP) return DGS_ERR_INVALID_ARGUMENT;
+  return DGS_OK;
+}
+
+int dgs_create(const dgs_params* params, dgs_handle** out) {
+  if (!params || !out || params->struct_size != sizeof(dgs_params)) return DGS_ERR_INVALID_ARGUMENT;
+  if (params->method != DGS_METHOD_NDT && params->method != DGS_METHOD_GICP) return DGS_ERR_INVALID_ARGUMENT;
+  if (!(params->ndt_resolution > 0) || params->maximum_iterations < 0 || params->gicp_correspondence_randomness < 1) return DGS_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  dgs_handle* h = new (std::nothrow) dgs_handle();
+  if (!h) return DGS_ERR_HIP;
+  h->prm = *params;
+  int dev = params->device;
+  hipError_t e = hipSuccess;
+  if (dev < 0) e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipSetDevice(dev);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {  // no usable HIP device: there is no CPU fallback
+    g_create_error = std::string("dgs_create(device=") + std::to_string(params->device) + "): " + hipGetErrorString(e);
+    delete h;
+    return DGS_ERR_HIP;
+  }
+  h->device = dev;
+  h->own_stream = true;
+  std::memset(h->final_T, 0, sizeof(h->final_T));
+  h->final_T[0] = h->final_T[5] = h->final_T[10] = h->final_T[15] = 1.f;
+  *out = h;
+  return DGS_OK;
+}
+
+void dgs_destroy(dgs_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->target.release(); h->source.release();
+  h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
+  h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
+  h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
+  h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->src_ptrs.release(); h->src_sizes.release();
+  h->target_bvh.sorted.release(); h->target_bvh.node_lo.release(); h->target_bvh.node_hi.release();
+  h->target_bvh.keys.release(); h->target_bvh.keys_alt.release(); h->target_bvh.vals.release(); h->target_bvh.vals_alt.release();
+  h->nn_partials.release(); h->scratch_cloud.release();
+  for (auto& ep : h->prof.pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* dgs_last_error(const dgs_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dgs_set_stream(dgs_handle* h, void* hip_stream) {
+  if (!h) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  if (hip_stream) {
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    h->own_stream = false;
+  } else {
+    DGS_HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  return DGS_OK;
+}
+
+int dgs_synchronize(dgs_handle* h) {
+  if (!h) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DGS_OK;
+}
+
+int dgs_set_input_target(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_device) {
+  if (!h || n < 0 || (n > 0 && !xyz16) || n > INT32_MAX) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  h->have_target = false;
+  h->target_bvh.valid = false;
+  h->nt = n;
+  int rc = upload_cloud(h, h->target, xyz16, n, on_device);
+  if (rc) return rc;
+  if (h->prm.method == DGS_METHOD_NDT) {
+    rc = ndt_build_target(h);
+    if (rc) return rc;
+  }
+  h->have_target = true;
+  return DGS_OK;
+}
+
+int dgs_set_input_source(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_device) {
+  if (!h || n < 0 || (n > 0 && !xyz16) || n > INT32_MAX) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  h->have_source = false;
+  h->ns = n;
+  int rc = upload_cloud(h, h->source, xyz16, n, on_device);
+  if (rc) return rc;
+  h->have_source = true;
+  return DGS_OK;
+}
+
+static void fail_result(dgs_result* r, const float* guess, int status) {
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::memcpy(r->final_transformation, guess ? guess : ident, sizeof(float) * 16);
+  r->converged = 0;
+  r->iterations = 0;
+  r->evaluations = 0;
+  r->status = status;
+  r->score = 0.0;
+  r->fitness = NAN;
+}
+
+int dgs_align(dgs_handle* h, const float* guess16, dgs_result* out, float* aligned, int32_t aligned_on_device) {
+  if (!h || !out) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  fail_result(out, guess16, DGS_OK);
+  if (set_device(h)) { out->status = DGS_ERR_HIP; return DGS_ERR_HIP; }
+  if (!h->have_target || h->nt == 0) { out->status = DGS_ERR_NO_TARGET; h->err = "no input target dataset was given"; return DGS_ERR_NO_TARGET; }
+  if (!h->have_source || h->ns == 0) { out->status = DGS_ERR_NO_SOURCE; h->err = "no input source dataset was given"; return DGS_ERR_NO_SOURCE; }
+  int rc;
+  if (h->prm.method == DGS_METHOD_NDT) {
+    const float4* src = h->source.ptr;
+    const int n = (int)h->ns;
+    rc = ndt_align_pairs(h, 1, &src, &n, guess16, out);
+  } else {
+    h->err = "FAST_GICP is not built into this library revision";
+    rc = DGS_ERR_UNSUPPORTED;
+  }
+  if (rc != DGS_OK) {
+    fail_result(out, guess16, rc);
+    return rc;
+  }
+  std::memcpy(h->final_T, out->final_transformation, sizeof(h->final_T));
+  h->have_result = true;
+  if (aligned) {
+    float4* dst = reinterpret_cast<float4*>(aligned);
+    if (!aligned_on_device) {
+      DGS_HIP_TRY(h, h->scratch_cloud.reserve((size_t)h->ns));
+      dst = h->scratch_cloud.ptr;
+    }
+    transform_cloud(h, h->source.ptr, dst, h->ns, h->final_T);
+    if (!aligned_on_device) {
+      DGS_HIP_TRY(h, hipMemcpyAsync(aligned, dst, (size_t)h->ns * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+      DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  return DGS_OK;
+}
+
+int dgs_get_fitness_score(dgs_handle* h, double max_range, double* score) {
+  if (!h || !score) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
+  if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
+  double sum = 0;
+  int64_t cnt = 0, inl = 0;
+  int rc = nn_fitness(h, h->source.ptr, h->ns, h->final_T, max_range, 0.0, &sum, &cnt, &inl);
+  if (rc) return rc;
+  *score = cnt > 0 ? sum / (double)cnt : DBL_MAX;
+  return DGS_OK;
+}
+
+int dgs_get_inlier_fraction(dgs_handle* h, double max_sq_dist, double* fraction) {
+  if (!h || !fraction) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
+  if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
+  double sum = 0;
+  int64_t cnt = 0, inl = 0;
+  int rc = nn_fitness(h, h->source.ptr, h->ns, h->final_T, DBL_MAX, max_sq_dist, &sum, &cnt, &inl);
+  if (rc) return rc;
+  *fraction = (double)inl / (double)h->ns;
+  return DGS_OK;
+}
+
+int dgs_nearest_search_target(dgs_handle* h, const float* queries, int64_t m, int32_t on_device, int32_t* indices, float* sq_dists) {
+  if (!h || m < 0 || (m > 0 && (!queries || !indices || !sq_dists))) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
+  if (m == 0) return DGS_OK;
+  const float4* dq = reinterpret_cast<const float4*>(queries);
+  int32_t* didx = indices;
+  float* dsq = sq_dists;
+  DevBuf<float4> q;
+  DevBuf<int32_t> bi;
+  DevBuf<float> bd;
+  int rc = DGS_OK;
+  if (!on_device) {
+    if (q.reserve(m) != hipSuccess || bi.reserve(m) != hipSuccess || bd.reserve(m) != hipSuccess) { h->err = "hipMalloc failed"; rc = DGS_ERR_HIP; }
+    if (!rc && hipMemcpyAsync(q.ptr, queries, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "hipMemcpyAsync failed"; rc = DGS_ERR_HIP; }
+    dq = q.ptr; didx = bi.ptr; dsq = bd.ptr;
+  }
+  if (!rc) rc = nn_search(h, dq, m, didx, dsq);
+  if (!rc && !on_device) {
+    if (hipMemcpyAsync(indices, didx, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(sq_dists, dsq, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { h->err = "hipMemcpyAsync failed"; rc = DGS_ERR_HIP; }
+  }
+  (void)hipStreamSynchronize(h->stream);
+  q.release(); bi.release(); bd.release();
+  return rc;
+}
+
+int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const int64_t* sizes, int32_t on_device, const float* guesses16,
+                    int32_t compute_fitness, double fitness_max_range, dgs_result* results) {
+  if (!h || n < 0 || (n > 0 && (!sources || !sizes || !results))) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (n == 0) return DGS_OK;
+  for (int i = 0; i < n; i++) fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_OK);
+  if (!h->have_target || h->nt == 0) {
+    for (int i = 0; i < n; i++) results[i].status = DGS_ERR_NO_TARGET;
+    h->err = "no input target dataset was given";
+    return DGS_ERR_NO_TARGET;
+  }
+  if (h->prm.method != DGS_METHOD_NDT) { h->err = "batched FAST_GICP is not built into this library revision"; return DGS_ERR_UNSUPPORTED; }
+  // stage sources on the device when they come from the host (one contiguous slab)
+  std::vector<const float4*> ptrs(n);
+  std::vector<int> sz(n);
+  DevBuf<float4> slab;
+  int64_t total = 0;
+  for (int i = 0; i < n; i++) {
+    if (sizes[i] < 0 || sizes[i] > INT32_MAX || (sizes[i] > 0 && !sources[i])) return DGS_ERR_INVALID_ARGUMENT;
+    sz[i] = (int)sizes[i];
+    total += sizes[i];
+  }
+  if (!on_device) {
+    DGS_HIP_TRY(h, slab.reserve((size_t)std::max<int64_t>(total, 1)));
+    int64_t off = 0;
+    for (int i = 0; i < n; i++) {
+      ptrs[i] = slab.ptr + off;
+      if (sz[i]) DGS_HIP_TRY(h, hipMemcpyAsync(slab.ptr + off, sources[i], (size_t)sz[i] * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+      off += sz[i];
+    }
+  } else {
+    for (int i = 0; i < n; i++) ptrs[i] = reinterpret_cast<const float4*>(sources[i]);
+  }
+  int rc = ndt_align_pairs(h, n, ptrs.data(), sz.data(), guesses16, results);
+  if (rc == DGS_OK && compute_fitness) {
+    // getFitnessScore for every candidate in one launch; transforms are read from the optimiser state in HBM
+    std::vector<double> sums(n);
+    std::vector<int64_t> cnts(n), inl(n);
+    int max_n = 0;
+    for (int i = 0; i < n; i++) max_n = std::max(max_n, sz[i]);
+    const float* dT = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->pairs.ptr) + offsetof(NdtPair, final_T));
+    rc = nn_fitness_batch(h, n, h->src_ptrs.ptr, h->src_sizes.ptr, max_n, dT, sizeof(NdtPair), fitness_max_range, 0.0, sums.data(), cnts.data(),
+                          inl.data());
+    if (rc == DGS_OK)
+      for (int i = 0; i < n; i++) results[i].fitness = cnts[i] > 0 ? sums[i] / (double)cnts[i] : DBL_MAX;
+  }
+  if (rc == DGS_OK) {
+    for (int i = 0; i < n; i++)
+      if (sz[i] == 0)  // PCL refuses an empty source (initCompute fails): not converged, transform = guess
+        fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_ERR_NO_SOURCE);
+  }
+  (void)hipStreamSynchronize(h->stream);
+  slab.release();
+  return rc;
+}
+
+int dgs_profile_enable(dgs_handle* h, int32_t enable) {
+  if (!h) return DGS_ERR_INVALID_ARGUMENT;
+  if (set_device(h)) return DGS_ERR_HIP;
+  prof_collect(h);
+  h->prof.enabled = enable != 0;
+  return DGS_OK;
+}
+
+int dgs_profile_get(dgs_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches) {
+  if (!h || kernel_id < 0 || kernel_id >= DGS_K_COUNT) return DGS_ERR_INVALID_ARGUMENT;
+  if (set_device(h)) return DGS_ERR_HIP;
+  prof_collect(h);
+  if (total_ms) *total_ms = h->prof.total_ms[kernel_id];
+  if (launches) *launches = h->prof.launches[kernel_id];
+  return DGS_OK;
+}
+
+int dgs_profile_reset(dgs_handle* h) {
+  if (!h) return DGS_ERR_INVALID_ARGUMENT;
+  if (set_device(h)) return DGS_ERR_HIP;
+  prof_collect(h);
+  for (int k = 0; k < DGS_K_COUNT; k++) { h->prof.total_ms[k] = 0; h->prof.launches[k] = 0; }
+  return DGS_OK;
+}
+
+int dgs_get_counts(dgs_handle* h, int64_t out[8]) {
+  if (!h || !out) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  out[0] = h->nt;
+  out[1] = h->ns;
+  if (h->prm.method == DGS_METHOD_NDT && h->have_target && h->grid_cells > 0) {
+    if (h->counts_stale) {
+      int sc[2] = {0, 0};
+      DGS_HIP_TRY(h, hipMemcpyAsync(sc, h->dev_scalars.ptr, sizeof(sc), hipMemcpyDeviceToHost, h->stream));
+      DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+      h->n_occupied = sc[0];
+      h->n_valid = sc[1];
+      h->counts_stale = false;
+    }
+    out[2] = h->n_valid;
+    out[3] = h->n_occupied;
+    out[4] = h->grid_cells;
+  }
+  out[5] = h->last_evaluations;
+  return DGS_OK;
+}
+
+int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, double* score, double* grad6, double* hess36) {
+  if (!h || !p6 || !score || !grad6 || !hess36) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (h->prm.method != DGS_METHOD_NDT) return DGS_ERR_UNSUPPORTED;
+  if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
+  if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
+  return ndt_probe(h, p6, T16, score, grad6, hess36);
+}
+
+int dgs_ndt_get_voxels(dgs_handle* h, int64_t* n, int64_t* keys, int32_t* counts, int32_t* valid, double* mean3, double* icov9) {
+  if (!h || !n) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (h->prm.method != DGS_METHOD_NDT) return DGS_ERR_UNSUPPORTED;
+  if (!h->have_target) return DGS_ERR_NO_TARGET;
+  int64_t c[8];
+  int rc = dgs_get_counts(h, c);
+  if (rc) return rc;
+  const int64_t nv = c[3];
+  *n = nv;
+  if (!keys || nv == 0) return DGS_OK;
+  std::vector<uint32_t> k32(nv);
+  std::vector<double> dbg((size_t)nv * 12);
+  DGS_HIP_TRY(h, hipMemcpy(k32.data(), h->run_keys.ptr, nv * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  DGS_HIP_TRY(h, hipMemcpy(counts, h->vox_count.ptr, nv * sizeof(int), hipMemcpyDeviceToHost));
+  DGS_HIP_TRY(h, hipMemcpy(valid, h->vox_valid.ptr, nv * sizeof(int), hipMemcpyDeviceToHost));
+  DGS_HIP_TRY(h, hipMemcpy(dbg.data(), h->vox_dbg.ptr, (size_t)nv * 12 * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < nv; i++) {
+    keys[i] = (k32[i] == 0xFFFFFFFFu) ? -1 : (int64_t)k32[i];
+    for (int a = 0; a < 3; a++) mean3[i * 3 + a] = dbg[i * 12 + a];
+    for (int a = 0; a < 9; a++) icov9[i * 9 + a] = dbg[i * 12 + 3 + a];
+  }
+  return DGS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// dgs_handle: per-registration-object state (one per pcl::Registration instance on the reference side).
+#pragma once
+#include "common.h"
+
+namespace dgs {
+
+struct EventPair {
+  hipEvent_t start, stop;
+};
+
+struct Profiler {
+  bool enabled = false;
+  std::vector<EventPair> pool;                 // all events ever created
+  std::vector<int> pending[DGS_K_COUNT];       // indices into pool, recorded but not yet read
+  size_t next_free = 0;
+  double total_ms[DGS_K_COUNT] = {0};
+  int64_t launches[DGS_K_COUNT] = {0};
+};
+
+// BVH over a point cloud (nn_bvh.hip): Morton-sorted points, implicit complete binary tree of AABBs.
+struct Bvh {
+  int64_t n = 0;            // points
+  int leaves = 0;           // number of leaf slots (power of two), each covers kLeafSize sorted points
+  int levels = 0;
+  float org[3] = {0, 0, 0};  // Morton quantisation origin / scale
+  float scale = 1.f;
+  DevBuf<float4> sorted;    // points in Morton order, w = original index (bit-cast int)
+  DevBuf<float4> node_lo;   // AABB min per node (heap order, root = 0); w unused
+  DevBuf<float4> node_hi;
+  DevBuf<uint32_t> keys, keys_alt;
+  DevBuf<uint32_t> vals, vals_alt;
+  bool valid = false;
+};
+
+}  // namespace dgs
+
+struct dgs_handle {
+  dgs_params prm;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // clouds (device copies, pcl::PointXYZ layout)
+  dgs::DevBuf<float4> target, source;
+  int64_t nt = 0, ns = 0;
+  bool have_target = false, have_source = false;
+
+  // ---- NDT target model
+  dgs::VoxelGrid grid{};
+  dgs::DevBuf<int> cell2vox;
+  dgs::DevBuf<dgs::VoxelRec> vox;
+  dgs::DevBuf<float4> vox_centroid;
+  dgs::DevBuf<double> vox_dbg;       // per occupied voxel: mean[3], icov[9]  (test hook)
+  dgs::DevBuf<int> vox_count;        // points per occupied voxel
+  dgs::DevBuf<int> vox_valid;
+  dgs::DevBuf<uint32_t> key_in, key_out, val_in, val_out, run_keys;
+  dgs::DevBuf<int> run_counts, run_offsets;
+  dgs::DevBuf<int> dev_scalars;      // [0]=num_runs, [1]=n_valid
+  dgs::DevBuf<float> minmax_partial; // block partials + final 6 floats
+  dgs::DevBuf<unsigned char> cub_temp;
+  int64_t grid_cells = 0;
+  int64_t n_occupied = 0, n_valid = 0;  // filled lazily by counts query
+  bool counts_stale = true;
+
+  // ---- NDT optimiser
+  dgs::DevBuf<dgs::NdtPair> pairs;
+  dgs::DevBuf<dgs::NdtInit> inits;
+  dgs::DevBuf<double> partials;       // [pair][block][kAccumPad]
+  dgs::DevBuf<int> done_counter;      // [0] = finished pairs
+  dgs::DevBuf<const float4*> src_ptrs;
+  dgs::DevBuf<int> src_sizes;
+  dgs::NdtConsts consts{};
+  int64_t last_evaluations = 0;
+
+  // pinned host staging
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+
+  // last result (single-pair API)
+  float final_T[16];
+  bool have_result = false;
+
+  // exact nearest-neighbour index over the target (lazy; rebuilt when the target changes)
+  dgs::Bvh target_bvh;
+  dgs::DevBuf<double> nn_partials;
+  dgs::DevBuf<float4> scratch_cloud;
+
+  dgs::Profiler prof;
+};
+
+namespace dgs {
+
+// profiling wrappers (dgs_api.hip)
+int prof_begin(dgs_handle* h, int kernel_id);
+void prof_end(dgs_handle* h, int kernel_id, int slot);
+int ensure_pinned(dgs_handle* h, size_t bytes);
+
+// ndt_voxel.hip
+int ndt_build_target(dgs_handle* h);
+int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]);
+// ndt_align.hip
+int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs_host, const int* sizes_host,
+                    const float* guesses16, dgs_result* results);
+int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36);
+// nn_bvh.hip
+int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n);
+int nn_fitness(dgs_handle* h, const float4* src, int64_t n, const float* T16, double max_range, double inlier_sq,
+               double* sum, int64_t* count, int64_t* inliers);
+// batched: device arrays of source pointers / sizes, device transforms (column-major 16 floats every T_stride_bytes)
+int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
+                     size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
+int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
+// transform
+int transform_cloud(dgs_handle* h, const float4* in, float4* out, int64_t n, const float* T16_colmajor_host);
+
+}  // namespace dgs

@@ -1,0 +1,830 @@
+// K2 ndt_derivatives + K3 ndt_solve: the NDT align() loop on the device.
+//
+// Replaces pclomp::NormalDistributionsTransform::computeTransformation, i.e. what
+// registration->align(*aligned, guess) runs at /root/reference/apps/scan_matching_odometry_nodelet.cpp:218 and
+// /root/reference/include/hdl_graph_slam/loop_detector.hpp:145 (object configured at
+// src/hdl_graph_slam/registrations.cpp:105-119).  Algorithm: SURVEY.md App. A.
+//
+// MI355X design
+//   * One launch of ndt_derivatives covers EVERY pair of a batch (blockIdx.y = pair) and every source point:
+//     coalesced 16-B loads of XYZ1 points, 7 (1/27) dependent 4-B cell lookups, 48-B voxel records from L2,
+//     float per-point math, double accumulation, wave shuffle -> LDS -> one 28-double partial row per block.
+//     No atomics: the rows are summed in a fixed order by ndt_solve, so results are bit-reproducible.
+//   * Per point the 7 voxels are folded first into A = sum w C, b = sum w C q, M = sum w d2 (Cq)(Cq)^T and then
+//     projected once through the point Jacobian:  g = J^T b,  H = J^T (A - M) J + b . d2T/dp2  -- algebraically
+//     the upstream per-voxel update (eq. 6.12/6.13) at ~1/3 of the flops.
+//   * ndt_solve (one workgroup per pair) finishes the reduction and runs Newton + the More-Thuente state
+//     machine on lane 0, then writes the next evaluation's float transform and angle tables in place, so an
+//     iteration is two dependent launches and NO host round trip; finished pairs turn their blocks into
+//     immediate returns.  The host only polls a "pairs done" counter once per chunk of iterations.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "handle.h"
+
+namespace dgs {
+
+// ================================================================================================ derivatives
+template <int SEARCH>
+struct Offsets;
+template <>
+struct Offsets<DGS_NDT_DIRECT1> {
+  static constexpr int N = 1;
+};
+template <>
+struct Offsets<DGS_NDT_DIRECT7> {
+  static constexpr int N = 7;
+};
+template <>
+struct Offsets<DGS_NDT_DIRECT26> {
+  static constexpr int N = 27;
+};
+template <>
+struct Offsets<DGS_NDT_KDTREE> {
+  static constexpr int N = 27;
+};
+
+template <int SEARCH>
+__device__ __forceinline__ void neighbour_offset(int k, int& dx, int& dy, int& dz) {
+  if (SEARCH == DGS_NDT_DIRECT1) {
+    dx = dy = dz = 0;
+  } else if (SEARCH == DGS_NDT_DIRECT7) {
+    // (0,0,0) (+x) (-x) (+y) (-y) (+z) (-z): pclomp getNeighborhoodAtPoint7 order
+    dx = (k == 1) - (k == 2);
+    dy = (k == 3) - (k == 4);
+    dz = (k == 5) - (k == 6);
+  } else {
+    dx = k / 9 - 1;
+    dy = (k / 3) % 3 - 1;
+    dz = k % 3 - 1;
+  }
+}
+
+template <int SEARCH>
+__global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
+                                                                 const NdtPair* __restrict__ pairs, const VoxelGrid g, const float gd1,
+                                                                 const float gd2, double* __restrict__ partials, const int blocks_per_pair) {
+  const int pair = blockIdx.y;
+  const NdtPair& st = pairs[pair];
+  if (!st.active) return;
+  const float4* __restrict__ src = src_ptrs[pair];
+  const int n = src_sizes[pair];
+  const bool need_h = st.need_hessian != 0;
+
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st.T[k];
+
+  double acc[kAccum];
+#pragma unroll
+  for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
+
+  const float r2 = g.leaf * g.leaf;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
+    const float4 x = src[i];
+    // pcl::transformPointCloud in float, ((m0 x + m1 y) + m2 z) + m3 with every step rounded (no FMA contraction):
+    // q = x' - mean is a cancellation, so one ulp of x' is ~1e-5 of a point's contribution -- keep x' exact.
+    const float xt0 = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
+    const float xt1 = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
+    const float xt2 = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
+    const int c0 = (int)floorf(xt0 / g.leaf), c1 = (int)floorf(xt1 / g.leaf), c2 = (int)floorf(xt2 / g.leaf);
+
+    // ---- gather: voxel ids of the neighbourhood (independent loads, issued together)
+    constexpr int NB = Offsets<SEARCH>::N;
+    int vid[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      int dx, dy, dz;
+      neighbour_offset<SEARCH>(k, dx, dy, dz);
+      const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
+      const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
+      vid[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+    }
+
+    // ---- fold the neighbourhood:  A = sum w C,  b = sum w C q,  M = sum w d2 (Cq)(Cq)^T,  score
+    float A[6] = {0, 0, 0, 0, 0, 0}, M[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, sc = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (vid[k] < 0) continue;
+      if (SEARCH == DGS_NDT_KDTREE) {
+        const float4 ce = g.centroid[vid[k]];
+        const float ex = ce.x - xt0, ey = ce.y - xt1, ez = ce.z - xt2;
+        if (!(ex * ex + ey * ey + ez * ez < r2)) continue;
+      }
+      const VoxelRec* __restrict__ rec = g.vox + vid[k];
+      const double2 m01 = *reinterpret_cast<const double2*>(&rec->mean[0]);
+      const double m2 = rec->mean[2];
+      const float4 ca = *reinterpret_cast<const float4*>(&rec->icov[0]);
+      const float2 cb = *reinterpret_cast<const float2*>(&rec->icov[4]);
+      const float q0 = (float)((double)xt0 - m01.x), q1 = (float)((double)xt1 - m01.y), q2 = (float)((double)xt2 - m2);
+      const float Cxx = ca.x, Cxy = ca.y, Cxz = ca.z, Cyy = ca.w, Cyz = cb.x, Czz = cb.y;
+      const float u0 = q0 * Cxx + q1 * Cxy + q2 * Cxz;
+      const float u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
+      const float u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
+      float e = expf(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
+      const float score_inc = -gd1 * e;
+      e = gd2 * e;
+      if (e > 1.f || e < 0.f || e != e) continue;  // upstream "error checking for invalid values"
+      const float w = e * gd1;
+      const float wd = w * gd2;
+      sc += score_inc;
+      any = true;
+      b[0] += w * u0; b[1] += w * u1; b[2] += w * u2;
+      A[0] += w * Cxx; A[1] += w * Cxy; A[2] += w * Cxz; A[3] += w * Cyy; A[4] += w * Cyz; A[5] += w * Czz;
+      M[0] += wd * u0 * u0; M[1] += wd * u0 * u1; M[2] += wd * u0 * u2; M[3] += wd * u1 * u1; M[4] += wd * u1 * u2; M[5] += wd * u2 * u2;
+    }
+    if (!any) continue;
+
+    // ---- project through the point Jacobian (eq. 6.18/6.19): J = [I | J3 J4 J5]
+    float xj[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xj[k] = st.jang[k][0] * x.x + st.jang[k][1] * x.y + st.jang[k][2] * x.z;
+    const float J3[3] = {0.f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
+    acc[0] += (double)sc;
+    acc[1] += (double)b[0];
+    acc[2] += (double)b[1];
+    acc[3] += (double)b[2];
+    acc[4] += (double)(b[1] * J3[1] + b[2] * J3[2]);
+    acc[5] += (double)(b[0] * J4[0] + b[1] * J4[1] + b[2] * J4[2]);
+    acc[6] += (double)(b[0] * J5[0] + b[1] * J5[1] + b[2] * J5[2]);
+    if (need_h) {
+      const float N0 = A[0] - M[0], N1 = A[1] - M[1], N2 = A[2] - M[2], N3 = A[3] - M[3], N4 = A[4] - M[4], N5 = A[5] - M[5];
+      // N * J_k
+      const float n3[3] = {N1 * J3[1] + N2 * J3[2], N3 * J3[1] + N4 * J3[2], N4 * J3[1] + N5 * J3[2]};
+      const float n4[3] = {N0 * J4[0] + N1 * J4[1] + N2 * J4[2], N1 * J4[0] + N3 * J4[1] + N4 * J4[2], N2 * J4[0] + N4 * J4[1] + N5 * J4[2]};
+      const float n5[3] = {N0 * J5[0] + N1 * J5[1] + N2 * J5[2], N1 * J5[0] + N3 * J5[1] + N4 * J5[2], N2 * J5[0] + N4 * J5[1] + N5 * J5[2]};
+      float xh[15];
+#pragma unroll
+      for (int k = 0; k < 15; k++) xh[k] = st.hang[k][0] * x.x + st.hang[k][1] * x.y + st.hang[k][2] * x.z;
+      // b . second derivatives: a=(0,xh0,xh1) b=(0,xh2,xh3) c=(0,xh4,xh5) d=(xh6..8) e=(xh9..11) f=(xh12..14)
+      const float ba = b[1] * xh[0] + b[2] * xh[1];
+      const float bb = b[1] * xh[2] + b[2] * xh[3];
+      const float bc = b[1] * xh[4] + b[2] * xh[5];
+      const float bd = b[0] * xh[6] + b[1] * xh[7] + b[2] * xh[8];
+      const float be = b[0] * xh[9] + b[1] * xh[10] + b[2] * xh[11];
+      const float bf = b[0] * xh[12] + b[1] * xh[13] + b[2] * xh[14];
+      // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+      acc[7] += (double)N0;  acc[8] += (double)N1;  acc[9] += (double)N2;  acc[10] += (double)n3[0]; acc[11] += (double)n4[0]; acc[12] += (double)n5[0];
+      acc[13] += (double)N3; acc[14] += (double)N4; acc[15] += (double)n3[1]; acc[16] += (double)n4[1]; acc[17] += (double)n5[1];
+      acc[18] += (double)N5; acc[19] += (double)n3[2]; acc[20] += (double)n4[2]; acc[21] += (double)n5[2];
+      acc[22] += (double)(J3[1] * n3[1] + J3[2] * n3[2] + ba);
+      acc[23] += (double)(J3[1] * n4[1] + J3[2] * n4[2] + bb);
+      acc[24] += (double)(J3[1] * n5[1] + J3[2] * n5[2] + bc);
+      acc[25] += (double)(J4[0] * n4[0] + J4[1] * n4[1] + J4[2] * n4[2] + bd);
+      acc[26] += (double)(J4[0] * n5[0] + J4[1] * n5[1] + J4[2] * n5[2] + be);
+      acc[27] += (double)(J5[0] * n5[0] + J5[1] * n5[1] + J5[2] * n5[2] + bf);
+    }
+  }
+
+  // ---- block reduction: wave shuffle -> LDS -> one row of kAccumPad doubles
+  __shared__ double sm[kBlock / kWave][kAccumPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kAccum; k++) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) sm[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumPad) {
+    double v = 0.0;
+    if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    partials[((size_t)pair * blocks_per_pair + blockIdx.x) * kAccumPad + threadIdx.x] = v;
+  }
+}
+
+// ================================================================================================ solver (lane 0)
+// Gaussian elimination with full pivoting on a 6x6; returns the smallest/largest |pivot| ratio in *rcond.
+__device__ void lu_solve6(const double* Ain, const double* b, double* x, double* rcond) {
+  double A[36], y[6];
+  int cp[6];
+  for (int i = 0; i < 36; i++) A[i] = Ain[i];
+  for (int i = 0; i < 6; i++) { y[i] = b[i]; cp[i] = i; }
+  double pmax = 0, pmin = DBL_MAX;
+  for (int k = 0; k < 6; k++) {
+    int pr = k, pc = k;
+    double best = -1;
+    for (int i = k; i < 6; i++)
+      for (int j = k; j < 6; j++)
+        if (fabs(A[i * 6 + j]) > best) { best = fabs(A[i * 6 + j]); pr = i; pc = j; }
+    if (pr != k) {
+      for (int j = 0; j < 6; j++) { const double t = A[k * 6 + j]; A[k * 6 + j] = A[pr * 6 + j]; A[pr * 6 + j] = t; }
+      const double t = y[k]; y[k] = y[pr]; y[pr] = t;
+    }
+    if (pc != k) {
+      for (int i = 0; i < 6; i++) { const double t = A[i * 6 + k]; A[i * 6 + k] = A[i * 6 + pc]; A[i * 6 + pc] = t; }
+      const int t = cp[k]; cp[k] = cp[pc]; cp[pc] = t;
+    }
+    const double piv = A[k * 6 + k];
+    pmax = fmax(pmax, fabs(piv));
+    pmin = fmin(pmin, fabs(piv));
+    if (piv == 0.0) continue;
+    for (int i = k + 1; i < 6; i++) {
+      const double l = A[i * 6 + k] / piv;
+      for (int j = k + 1; j < 6; j++) A[i * 6 + j] -= l * A[k * 6 + j];
+      y[i] -= l * y[k];
+    }
+  }
+  *rcond = (pmax > 0) ? pmin / pmax : 0.0;
+  double z[6];
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+    for (int j = i + 1; j < 6; j++) s -= A[i * 6 + j] * z[j];
+    z[i] = (A[i * 6 + i] != 0.0) ? s / A[i * 6 + i] : 0.0;
+  }
+  for (int i = 0; i < 6; i++) x[cp[i]] = z[i];
+}
+
+// Pseudo-inverse solve through a one-sided Jacobi SVD with Eigen::JacobiSVD's default rank threshold
+// (6 * eps * s_max).  Slow path: only taken when the elimination above meets a (numerically) singular Hessian.
+__device__ void svd_solve6_dev(const double* A, const double* b, double* x) {
+  double U[36], V[36];
+  for (int i = 0; i < 36; i++) { U[i] = A[i]; V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 40; sweep++) {
+    bool rotated = false;
+    for (int p = 0; p < 5; p++)
+      for (int q = p + 1; q < 6; q++) {
+        double al = 0, be = 0, ga = 0;
+        for (int k = 0; k < 6; k++) { al += U[k * 6 + p] * U[k * 6 + p]; be += U[k * 6 + q] * U[k * 6 + q]; ga += U[k * 6 + p] * U[k * 6 + q]; }
+        if (ga == 0.0 || fabs(ga) <= 4e-16 * sqrt(al * be)) continue;
+        rotated = true;
+        const double ze = (be - al) / (2.0 * ga);
+        const double t = (ze >= 0 ? 1.0 : -1.0) / (fabs(ze) + sqrt(1.0 + ze * ze));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int k = 0; k < 6; k++) {
+          const double up = U[k * 6 + p], uq = U[k * 6 + q];
+          U[k * 6 + p] = c * up - s * uq; U[k * 6 + q] = s * up + c * uq;
+          const double vp = V[k * 6 + p], vq = V[k * 6 + q];
+          V[k * 6 + p] = c * vp - s * vq; V[k * 6 + q] = s * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double sv[6], smax = 0;
+  for (int j = 0; j < 6; j++) {
+    double s2 = 0;
+    for (int k = 0; k < 6; k++) s2 += U[k * 6 + j] * U[k * 6 + j];
+    sv[j] = sqrt(s2);
+    smax = fmax(smax, sv[j]);
+  }
+  const double thr = fmax(smax * 6.0 * DBL_EPSILON, DBL_MIN);
+  for (int i = 0; i < 6; i++) x[i] = 0.0;
+  for (int j = 0; j < 6; j++) {
+    if (!(sv[j] > thr)) continue;
+    double ub = 0;
+    for (int k = 0; k < 6; k++) ub += U[k * 6 + j] * b[k];
+    const double coef = ub / (sv[j] * sv[j]);
+    for (int i = 0; i < 6; i++) x[i] += V[i * 6 + j] * coef;
+  }
+}
+
+// float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap)
+__device__ void write_evaluation(NdtPair& st, const NdtConsts& c, const double* x, int need_hessian, bool write_T) {
+  if (write_T) {
+    const float rx = (float)x[3], ry = (float)x[4], rz = (float)x[5];
+    const float cx = cosf(rx), sx = sinf(rx), cy = cosf(ry), sy = sinf(ry), cz = cosf(rz), sz = sinf(rz);
+    const float r00 = cy * cz, r01 = -cy * sz, r02 = sy;
+    const float r10 = cx * sz + sx * sy * cz, r11 = cx * cz - sx * sy * sz, r12 = -sx * cy;
+    const float r20 = sx * sz - cx * sy * cz, r21 = sx * cz + cx * sy * sz, r22 = cx * cy;
+    const float t0 = (float)x[0], t1 = (float)x[1], t2 = (float)x[2];
+    st.T[0] = r00; st.T[1] = r01; st.T[2] = r02; st.T[3] = t0;
+    st.T[4] = r10; st.T[5] = r11; st.T[6] = r12; st.T[7] = t1;
+    st.T[8] = r20; st.T[9] = r21; st.T[10] = r22; st.T[11] = t2;
+    float* F = st.final_T;  // column-major
+    F[0] = r00; F[1] = r10; F[2] = r20; F[3] = 0.f;
+    F[4] = r01; F[5] = r11; F[6] = r21; F[7] = 0.f;
+    F[8] = r02; F[9] = r12; F[10] = r22; F[11] = 0.f;
+    F[12] = t0; F[13] = t1; F[14] = t2; F[15] = 1.f;
+  }
+  double cx, cy, cz, sx, sy, sz;
+  if (fabs(x[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(x[3]); sx = sin(x[3]); }
+  if (fabs(x[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(x[4]); sy = sin(x[4]); }
+  if (fabs(x[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(x[5]); sz = sin(x[5]); }
+  float (*J)[3] = st.jang;
+  J[0][0] = (float)(-sx * sz + cx * sy * cz); J[0][1] = (float)(-sx * cz - cx * sy * sz); J[0][2] = (float)(-cx * cy);
+  J[1][0] = (float)(cx * sz + sx * sy * cz);  J[1][1] = (float)(cx * cz - sx * sy * sz);  J[1][2] = (float)(-sx * cy);
+  J[2][0] = (float)(-sy * cz);                J[2][1] = (float)(sy * sz);                 J[2][2] = (float)(cy);
+  J[3][0] = (float)(sx * cy * cz);            J[3][1] = (float)(-sx * cy * sz);           J[3][2] = (float)(sx * sy);
+  J[4][0] = (float)(-cx * cy * cz);           J[4][1] = (float)(cx * cy * sz);            J[4][2] = (float)(-cx * sy);
+  J[5][0] = (float)(-cy * sz);                J[5][1] = (float)(-cy * cz);                J[5][2] = 0.f;
+  J[6][0] = (float)(cx * cz - sx * sy * sz);  J[6][1] = (float)(-cx * sz - sx * sy * cz); J[6][2] = 0.f;
+  J[7][0] = (float)(sx * cz + cx * sy * sz);  J[7][1] = (float)(cx * sy * cz - sx * sz);  J[7][2] = 0.f;
+  float (*H)[3] = st.hang;
+  H[0][0] = (float)(-cx * sz - sx * sy * cz); H[0][1] = (float)(-cx * cz + sx * sy * sz); H[0][2] = (float)(sx * cy);    // a2
+  H[1][0] = (float)(-sx * sz + cx * sy * cz); H[1][1] = (float)(-cx * sy * sz - sx * cz); H[1][2] = (float)(-cx * cy);   // a3
+  H[2][0] = (float)(cx * cy * cz);            H[2][1] = (float)(-cx * cy * sz);           H[2][2] = (float)(cx * sy);    // b2
+  H[3][0] = (float)(sx * cy * cz);            H[3][1] = (float)(-sx * cy * sz);           H[3][2] = (float)(sx * sy);    // b3
+  H[4][0] = (float)(-sx * cz - cx * sy * sz); H[4][1] = (float)(sx * sz - cx * sy * cz);  H[4][2] = 0.f;                 // c2
+  H[5][0] = (float)(cx * cz - sx * sy * sz);  H[5][1] = (float)(-sx * sy * cz - cx * sz); H[5][2] = 0.f;                 // c3
+  // d1: upstream PCL / ndt_omp carry +sy in the z slot; the exact second derivative is -sy (dgs_params.ndt_fix_hessian_d1)
+  H[6][0] = (float)(-cy * cz);                H[6][1] = (float)(cy * sz);                 H[6][2] = (float)(c.fix_hessian_d1 ? -sy : sy);
+  H[7][0] = (float)(-sx * sy * cz);           H[7][1] = (float)(sx * sy * sz);            H[7][2] = (float)(sx * cy);    // d2
+  H[8][0] = (float)(cx * sy * cz);            H[8][1] = (float)(-cx * sy * sz);           H[8][2] = (float)(-cx * cy);   // d3
+  H[9][0] = (float)(sy * sz);                 H[9][1] = (float)(sy * cz);                 H[9][2] = 0.f;                 // e1
+  H[10][0] = (float)(-sx * cy * sz);          H[10][1] = (float)(-sx * cy * cz);          H[10][2] = 0.f;                // e2
+  H[11][0] = (float)(cx * cy * sz);           H[11][1] = (float)(cx * cy * cz);           H[11][2] = 0.f;                // e3
+  H[12][0] = (float)(-cy * cz);               H[12][1] = (float)(cy * sz);                H[12][2] = 0.f;                // f1
+  H[13][0] = (float)(-cx * sz - sx * sy * cz); H[13][1] = (float)(-cx * cz + sx * sy * sz); H[13][2] = 0.f;              // f2
+  H[14][0] = (float)(-sx * sz + cx * sy * cz); H[14][1] = (float)(-cx * sy * sz - sx * cz); H[14][2] = 0.f;              // f3
+  for (int k = 0; k < 6; k++) st.x_t[k] = x[k];
+  st.need_hessian = need_hessian;
+}
+
+// ---- More-Thuente helpers (More & Thuente 1994; Sun & Yuan 2006 eq. 2.4.x) ---------------------------------
+__device__ inline double mt_psi(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
+__device__ inline double mt_dpsi(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
+
+__device__ double mt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+  if (f_t > f_l) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    return (fabs(a_c - a_l) < fabs(a_q - a_l)) ? a_c : 0.5 * (a_q + a_c);
+  } else if (g_t * g_l < 0) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    return (fabs(a_c - a_t) >= fabs(a_s - a_t)) ? a_c : a_s;
+  } else if (fabs(g_t) <= fabs(g_l)) {
+    const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    const double w = sqrt(z * z - g_t * g_l);
+    const double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    const double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    const double a_n = (fabs(a_c - a_t) < fabs(a_s - a_t)) ? a_c : a_s;
+    return (a_t > a_l) ? fmin(a_t + 0.66 * (a_u - a_t), a_n) : fmax(a_t + 0.66 * (a_u - a_t), a_n);
+  }
+  const double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+  const double w = sqrt(z * z - g_t * g_u);
+  return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+}
+
+__device__ bool mt_update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t,
+                                   double g_t) {
+  if (f_t > f_l) {
+    a_u = a_t; f_u = f_t; g_u = g_t;
+    return false;
+  } else if (g_t * (a_l - a_t) > 0) {
+    a_l = a_t; f_l = f_t; g_l = g_t;
+    return false;
+  } else if (g_t * (a_l - a_t) < 0) {
+    a_u = a_l; f_u = f_l; g_u = g_l;
+    a_l = a_t; f_l = f_t; g_l = g_t;
+    return false;
+  }
+  return true;
+}
+
+constexpr double kMu = 1.e-4, kNu = 0.9;
+
+__device__ inline double dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+
+// Starts one outer iteration from (score, grad, hess) at st.p.  Returns true when an evaluation was queued,
+// false when the iteration finished without one (zero step) or the registration ended.
+__device__ bool begin_iteration(NdtPair& st, const NdtConsts& c) {
+  double neg_g[6], delta[6], rc;
+  for (int k = 0; k < 6; k++) neg_g[k] = -st.grad[k];
+  lu_solve6(st.hess, neg_g, delta, &rc);
+  if (!(rc > 1e-13)) svd_solve6_dev(st.hess, neg_g, delta);
+  double norm = sqrt(dot6(delta, delta));
+  if (norm == 0 || norm != norm) {
+    st.converged = (norm == norm) ? 1 : 0;
+    st.phase = PH_DONE;
+    return false;
+  }
+  for (int k = 0; k < 6; k++) st.dir[k] = delta[k] / norm;
+  // computeStepLengthMT(p, dir, norm, step_size, eps / 2, ...)
+  st.phi_0 = -st.score;
+  st.d_phi_0 = -dot6(st.grad, st.dir);
+  st.step_init = norm;
+  if (st.d_phi_0 >= 0) {
+    if (st.d_phi_0 == 0) {
+      st.a_t = 0;  // "not a descent direction": zero step, no evaluation
+      return false;
+    }
+    st.d_phi_0 = -st.d_phi_0;
+    for (int k = 0; k < 6; k++) st.dir[k] = -st.dir[k];
+  }
+  const double step_max = c.step_size, step_min = c.trans_eps / 2;
+  st.step_iterations = 0;
+  st.a_l = 0; st.a_u = 0;
+  st.f_l = mt_psi(0, st.phi_0, st.phi_0, st.d_phi_0, kMu);
+  st.g_l = mt_dpsi(st.d_phi_0, st.d_phi_0, kMu);
+  st.f_u = st.f_l;
+  st.g_u = st.g_l;
+  st.interval_converged = (c.line_search == DGS_NDT_LS_FIXED_STEP) ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
+  st.open_interval = 1;
+  double a_t = fmax(fmin(norm, step_max), step_min);
+  st.a_t = a_t;
+  double x[6];
+  for (int k = 0; k < 6; k++) x[k] = st.p[k] + st.dir[k] * a_t;
+  write_evaluation(st, c, x, 1, true);
+  st.phase = PH_MT_FIRST;
+  return true;
+}
+
+// p += a_t * dir; convergence test of computeTransformation.  Returns true when the registration ended.
+__device__ bool end_iteration(NdtPair& st, const NdtConsts& c) {
+  const double a = st.a_t;
+  for (int k = 0; k < 6; k++) st.p[k] += st.dir[k] * a;
+  bool conv = false;
+  if (st.nr_iterations > c.max_iterations || (st.nr_iterations && (fabs(a) < c.trans_eps))) conv = true;
+  st.nr_iterations++;
+  if (conv) {
+    st.converged = 1;
+    st.phase = PH_DONE;
+  }
+  return conv;
+}
+
+__device__ inline bool mt_keep_going(const NdtPair& st, const NdtConsts& c, double psi_t, double d_phi_t) {
+  return !st.interval_converged && st.step_iterations < c.mt_max_step_iterations && !(psi_t <= 0 && d_phi_t <= -kNu * st.d_phi_0);
+}
+
+__device__ void queue_trial(NdtPair& st, const NdtConsts& c, double a_t) {
+  const double step_max = c.step_size, step_min = c.trans_eps / 2;
+  a_t = fmax(fmin(a_t, step_max), step_min);
+  st.a_t = a_t;
+  double x[6];
+  for (int k = 0; k < 6; k++) x[k] = st.p[k] + st.dir[k] * a_t;
+  write_evaluation(st, c, x, 0, true);
+  st.phase = PH_MT_TRIAL;
+}
+
+// Consumes one evaluation result (already stored in st.score/grad/hess) and advances the state machine until
+// the next evaluation is queued or the registration is finished.
+__device__ void ndt_advance(NdtPair& st, const NdtConsts& c) {
+  st.evaluations++;
+  bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
+  switch (st.phase) {
+    case PH_PROBE:
+      st.phase = PH_DONE;
+      return;
+    case PH_INIT_EVAL:
+      break;
+    case PH_MT_FIRST:
+    case PH_MT_TRIAL: {
+      const double phi_t = -st.score;
+      const double d_phi_t = -dot6(st.grad, st.dir);
+      const double psi_t = mt_psi(st.a_t, phi_t, st.phi_0, st.d_phi_0, kMu);
+      const double d_psi_t = mt_dpsi(d_phi_t, st.d_phi_0, kMu);
+      if (st.phase == PH_MT_TRIAL) {
+        if (st.open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+          st.open_interval = 0;
+          st.f_l = st.f_l + st.phi_0 - kMu * st.d_phi_0 * st.a_l;
+          st.g_l = st.g_l + kMu * st.d_phi_0;
+          st.f_u = st.f_u + st.phi_0 - kMu * st.d_phi_0 * st.a_u;
+          st.g_u = st.g_u + kMu * st.d_phi_0;
+        }
+        if (st.open_interval)
+          st.interval_converged = mt_update_interval(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, psi_t, d_psi_t);
+        else
+          st.interval_converged = mt_update_interval(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, phi_t, d_phi_t);
+        st.step_iterations++;
+      }
+      if (mt_keep_going(st, c, psi_t, d_phi_t)) {
+        const double a_n = st.open_interval ? mt_trial_value(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, psi_t, d_psi_t)
+                                            : mt_trial_value(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, phi_t, d_phi_t);
+        queue_trial(st, c, a_n);
+        return;
+      }
+      if (st.step_iterations) {  // computeHessian at the accepted point
+        write_evaluation(st, c, st.x_t, 1, false);
+        st.phase = PH_MT_HESSIAN;
+        return;
+      }
+      iteration_open = true;
+    } break;
+    case PH_MT_HESSIAN:
+      iteration_open = true;
+      break;
+    default:
+      return;
+  }
+  for (int guard = 0; guard < 4096; guard++) {
+    if (iteration_open) {
+      if (end_iteration(st, c)) return;
+    }
+    if (begin_iteration(st, c)) return;  // evaluation queued
+    if (st.phase == PH_DONE) return;
+    iteration_open = true;               // zero-step iteration: close it and try again
+  }
+  st.converged = 0;
+  st.phase = PH_DONE;
+}
+
+__global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int blocks_per_pair,
+                                                           const NdtConsts c, int* __restrict__ done_counter) {
+  const int pair = blockIdx.x;
+  NdtPair& st = pairs[pair];
+  if (!st.active) return;
+  // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
+  __shared__ double sm[kBlock / kAccumPad][kAccumPad];
+  const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
+  constexpr int G = kBlock / kAccumPad;
+  double v = 0.0;
+  const double* base = partials + (size_t)pair * blocks_per_pair * kAccumPad;
+  for (int b = grp; b < blocks_per_pair; b += G) v += base[(size_t)b * kAccumPad + col];
+  sm[grp][col] = v;
+  __syncthreads();
+  __shared__ double tot[kAccumPad];
+  if (threadIdx.x < kAccumPad) {
+    double t = 0.0;
+    for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  st.score = tot[0];
+  for (int k = 0; k < 6; k++) st.grad[k] = tot[1 + k];
+  if (st.need_hessian) {
+    int q = 7;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        st.hess[i * 6 + j] = tot[q];
+        st.hess[j * 6 + i] = tot[q];
+        q++;
+      }
+  }
+  ndt_advance(st, c);
+  if (st.phase == PH_DONE) {
+    st.active = 0;
+    atomicAdd(done_counter, 1);
+  }
+}
+
+// ================================================================================================ init / export
+__global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __restrict__ inits, int n_pairs, const NdtConsts c, int probe) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  NdtPair& st = pairs[i];
+  const NdtInit& in = inits[i];
+  for (int k = 0; k < 6; k++) st.p[k] = in.p0[k];
+  write_evaluation(st, c, in.p0, 1, false);
+  // the first evaluation transforms the cloud by the GUESS matrix itself (computeTransformation)
+  const float* G = in.guess;
+  st.T[0] = G[0]; st.T[1] = G[4]; st.T[2] = G[8];  st.T[3] = G[12];
+  st.T[4] = G[1]; st.T[5] = G[5]; st.T[6] = G[9];  st.T[7] = G[13];
+  st.T[8] = G[2]; st.T[9] = G[6]; st.T[10] = G[10]; st.T[11] = G[14];
+  for (int k = 0; k < 16; k++) st.final_T[k] = G[k];
+  st.phase = probe ? PH_PROBE : PH_INIT_EVAL;
+  st.active = 1;
+  st.nr_iterations = 0;
+  st.evaluations = 0;
+  st.converged = 0;
+  st.step_iterations = 0;
+  st.interval_converged = 0;
+  st.open_interval = 1;
+  st.score = 0;
+  st.a_t = 0;
+  for (int k = 0; k < 6; k++) { st.grad[k] = 0; st.dir[k] = 0; }
+  for (int k = 0; k < 36; k++) st.hess[k] = 0;
+}
+
+struct NdtOut {
+  float T[16];
+  int converged, iterations, evaluations, pad;
+  double score;
+};
+
+__global__ void ndt_export_kernel(const NdtPair* __restrict__ pairs, int n_pairs, NdtOut* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const NdtPair& st = pairs[i];
+  NdtOut o;
+  for (int k = 0; k < 16; k++) o.T[k] = st.final_T[k];
+  o.converged = (st.phase == PH_DONE) ? st.converged : 0;
+  o.iterations = st.nr_iterations;
+  o.evaluations = st.evaluations;
+  o.pad = 0;
+  o.score = st.score;
+  out[i] = o;
+}
+
+// ================================================================================================ host side
+// Eigen 3.3 Matrix3f::eulerAngles(0,1,2) on the rotation block of a column-major float 4x4
+// (computeTransformation: "convert initial guess matrix to 6 element transformation vector").
+static void euler_angles_012(const float* T, float res[3]) {
+  auto m = [&](int r, int c) { return T[c * 4 + r]; };
+  const float kPi = 3.14159265358979323846f;
+  res[0] = std::atan2(m(1, 2), m(2, 2));
+  const float c2 = std::sqrt(m(0, 0) * m(0, 0) + m(0, 1) * m(0, 1));
+  if (res[0] > 0.0f) {
+    res[0] -= kPi;
+    res[1] = std::atan2(-m(0, 2), -c2);
+  } else {
+    res[1] = std::atan2(-m(0, 2), c2);
+  }
+  const float s1 = std::sin(res[0]), c1 = std::cos(res[0]);
+  res[2] = std::atan2(s1 * m(2, 0) - c1 * m(1, 0), c1 * m(1, 1) - s1 * m(2, 1));
+  res[0] = -res[0];
+  res[1] = -res[1];
+  res[2] = -res[2];
+}
+
+static void fill_consts(dgs_handle* h) {
+  const dgs_params& p = h->prm;
+  const double c1 = 10.0 * (1.0 - p.ndt_outlier_ratio);
+  const double c2 = p.ndt_outlier_ratio / std::pow(p.ndt_resolution, 3);
+  const double d3 = -std::log(c2);
+  NdtConsts& c = h->consts;
+  c.gauss_d1 = -std::log(c1 + c2) - d3;
+  c.gauss_d2 = -2.0 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / c.gauss_d1);
+  c.step_size = p.ndt_step_size;
+  c.trans_eps = p.transformation_epsilon;
+  c.max_iterations = p.maximum_iterations;
+  c.line_search = p.ndt_line_search;
+  c.mt_max_step_iterations = p.ndt_mt_max_step_iterations;
+  c.fix_hessian_d1 = p.ndt_fix_hessian_d1;
+  c.search_method = p.ndt_search_method;
+}
+
+static void launch_derivatives(dgs_handle* h, int n_pairs, int bpp) {
+  const dim3 grid(bpp, n_pairs), block(kBlock);
+  const float gd1 = (float)h->consts.gauss_d1, gd2 = (float)h->consts.gauss_d2;
+  int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES);
+  switch (h->consts.search_method) {
+    case DGS_NDT_DIRECT1:
+      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT1>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
+                         gd1, gd2, h->partials.ptr, bpp);
+      break;
+    case DGS_NDT_DIRECT26:
+      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT26>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
+                         gd1, gd2, h->partials.ptr, bpp);
+      break;
+    case DGS_NDT_KDTREE:
+      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_KDTREE>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
+                         gd1, gd2, h->partials.ptr, bpp);
+      break;
+    default:
+      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT7>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
+                         gd1, gd2, h->partials.ptr, bpp);
+      break;
+  }
+  prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
+}
+
+static void launch_solve(dgs_handle* h, int n_pairs, int bpp) {
+  int slot = prof_begin(h, DGS_K_NDT_SOLVE);
+  hipLaunchKernelGGL(ndt_solve_kernel, dim3(n_pairs), dim3(kBlock), 0, h->stream, h->pairs.ptr, h->partials.ptr, bpp, h->consts, h->done_counter.ptr);
+  prof_end(h, DGS_K_NDT_SOLVE, slot);
+}
+
+static int choose_blocks_per_pair(int n_pairs, int max_n) {
+  const int full = std::max(1, (max_n + kBlock - 1) / kBlock);     // one point per lane
+  const int share = std::max(8, 2048 / std::max(1, n_pairs));      // keep the whole launch near 2048 workgroups
+  return std::max(1, std::min(std::min(full, share), kMaxPartialBlocks));
+}
+
+// Uploads pointers / sizes / initial poses, runs init, returns blocks-per-pair.
+static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_host, const int* sizes_host, const float* guesses16,
+                     const double* probe_p6, int* bpp_out) {
+  hipStream_t st = h->stream;
+  fill_consts(h);
+  int max_n = 0;
+  for (int i = 0; i < n_pairs; i++) max_n = std::max(max_n, sizes_host[i]);
+  const int bpp = choose_blocks_per_pair(n_pairs, max_n);
+  *bpp_out = bpp;
+  DGS_HIP_TRY(h, h->pairs.reserve(n_pairs));
+  DGS_HIP_TRY(h, h->inits.reserve(n_pairs));
+  DGS_HIP_TRY(h, h->src_ptrs.reserve(n_pairs));
+  DGS_HIP_TRY(h, h->src_sizes.reserve(n_pairs));
+  DGS_HIP_TRY(h, h->partials.reserve((size_t)n_pairs * bpp * kAccumPad));
+  DGS_HIP_TRY(h, h->done_counter.reserve(16));
+  const size_t off_init = 256;
+  const size_t off_ptr = off_init + sizeof(NdtInit) * n_pairs;
+  const size_t off_size = off_ptr + sizeof(void*) * n_pairs;
+  const size_t off_out = (off_size + sizeof(int) * n_pairs + 255) & ~(size_t)255;
+  const size_t total = off_out + sizeof(NdtOut) * n_pairs + sizeof(NdtPair) + 256;
+  if (ensure_pinned(h, total) != DGS_OK) return DGS_ERR_HIP;
+  char* base = reinterpret_cast<char*>(h->pinned);
+  NdtInit* hin = reinterpret_cast<NdtInit*>(base + off_init);
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (int i = 0; i < n_pairs; i++) {
+    const float* G = guesses16 ? guesses16 + 16 * i : ident;
+    std::memcpy(hin[i].guess, G, sizeof(float) * 16);
+    if (probe_p6) {
+      for (int k = 0; k < 6; k++) hin[i].p0[k] = probe_p6[k];
+    } else {
+      float e[3];
+      euler_angles_012(G, e);
+      hin[i].p0[0] = G[12]; hin[i].p0[1] = G[13]; hin[i].p0[2] = G[14];
+      hin[i].p0[3] = e[0]; hin[i].p0[4] = e[1]; hin[i].p0[5] = e[2];
+    }
+  }
+  std::memcpy(base + off_ptr, src_ptrs_host, sizeof(void*) * n_pairs);
+  std::memcpy(base + off_size, sizes_host, sizeof(int) * n_pairs);
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, hin, sizeof(NdtInit) * n_pairs, hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->src_ptrs.ptr, base + off_ptr, sizeof(void*) * n_pairs, hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->src_sizes.ptr, base + off_size, sizeof(int) * n_pairs, hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->done_counter.ptr, 0, 16 * sizeof(int), st));
+  hipLaunchKernelGGL(ndt_init_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->pairs.ptr, h->inits.ptr, n_pairs, h->consts, probe_p6 ? 1 : 0);
+  return DGS_OK;
+}
+
+int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_host, const int* sizes_host, const float* guesses16,
+                    dgs_result* results) {
+  hipStream_t st = h->stream;
+  int bpp = 1;
+  int rc = ndt_setup(h, n_pairs, src_ptrs_host, sizes_host, guesses16, nullptr, &bpp);
+  if (rc != DGS_OK) return rc;
+
+  // ---- iterate: chunks of (derivatives, solve) launches; the host looks at the done counter one chunk behind
+  volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);  // [0], [1]: done counts of alternating chunks
+  flags[0] = flags[1] = 0;
+  hipEvent_t ev[2];
+  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  const int per_iter = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
+  const long max_evals = (long)(h->prm.maximum_iterations + 3) * per_iter + 2;
+  const int chunk = (n_pairs == 1) ? 6 : 8;
+  long queued = 0;
+  auto enqueue_chunk = [&](int slot) -> int {
+    for (int e = 0; e < chunk; e++) {
+      launch_derivatives(h, n_pairs, bpp);
+      launch_solve(h, n_pairs, bpp);
+    }
+    queued += chunk;
+    DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+    DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
+    return DGS_OK;
+  };
+  int cur = 0;
+  rc = enqueue_chunk(0);
+  bool finished = false;
+  while (rc == DGS_OK) {
+    const bool more = queued < max_evals;
+    if (more) rc = enqueue_chunk(cur ^ 1);
+    if (rc != DGS_OK) break;
+    hipError_t e = hipEventSynchronize(ev[cur]);
+    if (e != hipSuccess) { h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; break; }
+    if (flags[cur] >= n_pairs) { finished = true; break; }
+    if (!more) break;
+    cur ^= 1;
+  }
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  if (rc != DGS_OK) return rc;
+  (void)finished;  // pairs that did not finish inside max_evals export converged = 0
+
+  // ---- export
+  char* base = reinterpret_cast<char*>(h->pinned);
+  const size_t off_out = ((256 + sizeof(NdtInit) * n_pairs + sizeof(void*) * n_pairs + sizeof(int) * n_pairs) + 255) & ~(size_t)255;
+  NdtOut* hout = reinterpret_cast<NdtOut*>(base + off_out);
+  NdtOut* dout = reinterpret_cast<NdtOut*>(h->partials.ptr);  // partial rows are dead now; reuse (>= 32 doubles per pair)
+  hipLaunchKernelGGL(ndt_export_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->pairs.ptr, n_pairs, dout);
+  DGS_HIP_TRY(h, hipMemcpyAsync(hout, dout, sizeof(NdtOut) * n_pairs, hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipStreamSynchronize(st));
+  DGS_HIP_TRY(h, hipGetLastError());
+  int64_t evals = 0;
+  for (int i = 0; i < n_pairs; i++) {
+    std::memcpy(results[i].final_transformation, hout[i].T, sizeof(float) * 16);
+    results[i].converged = hout[i].converged;
+    results[i].iterations = hout[i].iterations;
+    results[i].evaluations = hout[i].evaluations;
+    results[i].status = DGS_OK;
+    results[i].score = hout[i].score;
+    results[i].fitness = NAN;
+    evals += hout[i].evaluations;
+  }
+  h->last_evaluations = evals;
+  return DGS_OK;
+}
+
+// Test hook: one computeDerivatives evaluation on the device.
+int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36) {
+  hipStream_t st = h->stream;
+  int bpp = 1;
+  const float4* src = h->source.ptr;
+  const int n = (int)h->ns;
+  float T[16];
+  if (T16) {
+    std::memcpy(T, T16, sizeof(T));
+  } else {  // pose_to_matrix in float, as the solver builds it
+    const float rx = (float)p6[3], ry = (float)p6[4], rz = (float)p6[5];
+    const float cx = std::cos(rx), sx = std::sin(rx), cy = std::cos(ry), sy = std::sin(ry), cz = std::cos(rz), sz = std::sin(rz);
+    T[0] = cy * cz; T[4] = -cy * sz; T[8] = sy; T[12] = (float)p6[0];
+    T[1] = cx * sz + sx * sy * cz; T[5] = cx * cz - sx * sy * sz; T[9] = -sx * cy; T[13] = (float)p6[1];
+    T[2] = sx * sz - cx * sy * cz; T[6] = sx * cz + cx * sy * sz; T[10] = cx * cy; T[14] = (float)p6[2];
+    T[3] = T[7] = T[11] = 0.f; T[15] = 1.f;
+  }
+  int rc = ndt_setup(h, 1, &src, &n, T, p6, &bpp);
+  if (rc != DGS_OK) return rc;
+  launch_derivatives(h, 1, bpp);
+  launch_solve(h, 1, bpp);
+  char* base = reinterpret_cast<char*>(h->pinned);
+  NdtPair* hp = reinterpret_cast<NdtPair*>(base + ((h->pinned_bytes - sizeof(NdtPair) - 64) & ~(size_t)63));
+  DGS_HIP_TRY(h, hipMemcpyAsync(hp, h->pairs.ptr, sizeof(NdtPair), hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipStreamSynchronize(st));
+  DGS_HIP_TRY(h, hipGetLastError());
+  *score = hp->score;
+  for (int k = 0; k < 6; k++) g6[k] = hp->grad[k];
+  for (int k = 0; k < 36; k++) H36[k] = hp->hess[k];
+  return DGS_OK;
+}
+
+}  // namespace dgs

@@ -1,0 +1,341 @@
+// K1 ndt_voxel_build: target cloud -> voxel-Gaussian model (pclomp::VoxelGridCovariance semantics).
+//
+// Replaces the work registration->setInputTarget() triggers for NDT_OMP
+// (/root/reference/apps/scan_matching_odometry_nodelet.cpp:180,254; include/hdl_graph_slam/loop_detector.hpp:124;
+// configured at src/hdl_graph_slam/registrations.cpp:105-119).  Algorithm: SURVEY.md App. A "Target model".
+//
+// MI355X design: the per-voxel moments are accumulated in double IN POINT-INDEX ORDER (stable radix sort by
+// voxel key, then one lane walks each voxel's run), so the table is bit-reproducible and follows the
+// upstream accumulation order -- no float/double atomics.  The table is tiny (V ~ 10^4 x 48 B) and lives in
+// L2; the dense cell->voxel index costs 4 B per grid cell of HBM (288 GB makes that free).
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <cmath>
+
+#include "handle.h"
+
+namespace dgs {
+
+// ---- AABB of the finite points ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void minmax_kernel(const float4* __restrict__ pts, int64_t n, float* __restrict__ partial) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+      mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+  __shared__ float sm[kBlock / kWave][6];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_down(mn[a], off, 64));
+      mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, 64));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int a = 0; a < 3; a++) { sm[wave][a] = mn[a]; sm[wave][3 + a] = mx[a]; }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = sm[0][threadIdx.x];
+    for (int w = 1; w < kBlock / kWave; w++) v = (threadIdx.x < 3) ? fminf(v, sm[w][threadIdx.x]) : fmaxf(v, sm[w][threadIdx.x]);
+    partial[blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+__global__ void minmax_final_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out6) {
+  const int t = threadIdx.x;
+  if (t < 6) {
+    float v = partial[t];
+    for (int b = 1; b < nblocks; b++) v = (t < 3) ? fminf(v, partial[b * 6 + t]) : fmaxf(v, partial[b * 6 + t]);
+    out6[t] = v;
+  }
+}
+
+// AABB of the finite points of a device cloud -> host (one stream sync).
+int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]) {
+  hipStream_t st = h->stream;
+  const int mm_blocks = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, 512);
+  DGS_HIP_TRY(h, h->minmax_partial.reserve((size_t)mm_blocks * 6 + 8));
+  if (ensure_pinned(h, 4096) != DGS_OK) return DGS_ERR_HIP;
+  float* d_final = h->minmax_partial.ptr + (size_t)mm_blocks * 6;
+  hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks), dim3(kBlock), 0, st, pts, n, h->minmax_partial.ptr);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, h->minmax_partial.ptr, mm_blocks, d_final);
+  float* hmm = reinterpret_cast<float*>(h->pinned);
+  DGS_HIP_TRY(h, hipMemcpyAsync(hmm, d_final, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipStreamSynchronize(st));
+  for (int k = 0; k < 6; k++) out6[k] = hmm[k];
+  return DGS_OK;
+}
+
+// ---- voxel key per point (VoxelGridCovariance first pass, index arithmetic in float as upstream) ---------
+__global__ __launch_bounds__(kBlock) void voxel_key_kernel(const float4* __restrict__ pts, int64_t n, VoxelGrid g,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  uint32_t key = 0xFFFFFFFFu;
+  if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+    const int i0 = (int)(floorf(p.x * g.inv_leaf) - (float)g.min_b[0]);
+    const int i1 = (int)(floorf(p.y * g.inv_leaf) - (float)g.min_b[1]);
+    const int i2 = (int)(floorf(p.z * g.inv_leaf) - (float)g.min_b[2]);
+    key = (uint32_t)(i0 + i1 * g.mul1 + i2 * g.mul2);
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kBlock) void gather_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ order, int64_t n,
+                                                        float4* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = pts[order[i]];
+}
+
+// ---- small double linear algebra on one lane ---------------------------------------------------------------
+__device__ inline bool inv3_d(const double* A, double* Ai) {
+  const double c00 = A[4] * A[8] - A[5] * A[7];
+  const double c01 = A[5] * A[6] - A[3] * A[8];
+  const double c02 = A[3] * A[7] - A[4] * A[6];
+  const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  const double id = 1.0 / det;
+  Ai[0] = c00 * id;
+  Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+  Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Ai[3] = c01 * id;
+  Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+  Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Ai[6] = c02 * id;
+  Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+  Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  return det != 0.0;
+}
+
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi, lower triangle is authoritative), ascending eigenvalues
+__device__ inline void sym_eig3_d(const double* Ain, double* ev, double* V) {
+  double a00 = Ain[0], a11 = Ain[4], a22 = Ain[8], a01 = Ain[3], a02 = Ain[6], a12 = Ain[7];
+  double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int sweep = 0; sweep < 32; sweep++) {
+    const double off = a01 * a01 + a02 * a02 + a12 * a12;
+    const double dia = a00 * a00 + a11 * a11 + a22 * a22;
+    if (off == 0.0 || off <= 1e-34 * dia) break;
+    // rotation (0,1)
+    if (a01 != 0.0) {
+      const double th = (a11 - a00) / (2.0 * a01);
+      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      const double n00 = a00 - t * a01, n11 = a11 + t * a01;
+      const double n02 = c * a02 - s * a12, n12 = s * a02 + c * a12;
+      a00 = n00; a11 = n11; a01 = 0.0; a02 = n02; a12 = n12;
+      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 0], y = v[k * 3 + 1]; v[k * 3 + 0] = c * x - s * y; v[k * 3 + 1] = s * x + c * y; }
+    }
+    // rotation (0,2)
+    if (a02 != 0.0) {
+      const double th = (a22 - a00) / (2.0 * a02);
+      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      const double n00 = a00 - t * a02, n22 = a22 + t * a02;
+      const double n01 = c * a01 - s * a12, n12 = s * a01 + c * a12;
+      a00 = n00; a22 = n22; a02 = 0.0; a01 = n01; a12 = n12;
+      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 0], y = v[k * 3 + 2]; v[k * 3 + 0] = c * x - s * y; v[k * 3 + 2] = s * x + c * y; }
+    }
+    // rotation (1,2)
+    if (a12 != 0.0) {
+      const double th = (a22 - a11) / (2.0 * a12);
+      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      const double n11 = a11 - t * a12, n22 = a22 + t * a12;
+      const double n01 = c * a01 - s * a02, n02 = s * a01 + c * a02;
+      a11 = n11; a22 = n22; a12 = 0.0; a01 = n01; a02 = n02;
+      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 1], y = v[k * 3 + 2]; v[k * 3 + 1] = c * x - s * y; v[k * 3 + 2] = s * x + c * y; }
+    }
+  }
+  double e[3] = {a00, a11, a22};
+  int o0 = 0, o1 = 1, o2 = 2;
+  if (e[o0] > e[o1]) { int t = o0; o0 = o1; o1 = t; }
+  if (e[o1] > e[o2]) { int t = o1; o1 = o2; o2 = t; }
+  if (e[o0] > e[o1]) { int t = o0; o0 = o1; o1 = t; }
+  const int o[3] = {o0, o1, o2};
+  for (int k = 0; k < 3; k++) {
+    ev[k] = e[o[k]];
+    for (int r = 0; r < 3; r++) V[r * 3 + k] = v[r * 3 + o[k]];
+  }
+}
+
+// ---- second pass: one lane per occupied voxel ----------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __restrict__ sorted_pts, const uint32_t* __restrict__ run_keys,
+                                                                const int* __restrict__ run_counts, const int* __restrict__ run_offsets,
+                                                                int* __restrict__ scalars, int min_points, double eig_mult,
+                                                                int* __restrict__ cell2vox, VoxelRec* __restrict__ vox,
+                                                                float4* __restrict__ centroid, double* __restrict__ dbg,
+                                                                int* __restrict__ vcount, int* __restrict__ vvalid) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int num_runs = scalars[0];
+  if (r >= num_runs) return;
+  const uint32_t key = run_keys[r];
+  const int cnt = run_counts[r];
+  vcount[r] = cnt;
+  vvalid[r] = 0;
+  if (key == 0xFFFFFFFFu) {  // non-finite points
+    vcount[r] = 0;
+    return;
+  }
+  const int off = run_offsets[r];
+  double s[3] = {0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0};
+  float cf[3] = {0, 0, 0};
+  for (int j = 0; j < cnt; j++) {
+    const float4 p = sorted_pts[off + j];
+    const double x = p.x, y = p.y, z = p.z;
+    s[0] += x; s[1] += y; s[2] += z;
+    q[0] += x * x; q[1] += x * y; q[2] += x * z; q[3] += y * y; q[4] += y * z; q[5] += z * z;
+    cf[0] += p.x; cf[1] += p.y; cf[2] += p.z;
+  }
+  const double np = (double)cnt;
+  const double mean[3] = {s[0] / np, s[1] / np, s[2] / np};
+  const float fn = (float)cnt;
+  double* d = dbg + (size_t)r * 12;
+  d[0] = mean[0]; d[1] = mean[1]; d[2] = mean[2];
+  for (int k = 0; k < 9; k++) d[3 + k] = 0.0;
+  VoxelRec rec;
+  rec.mean[0] = mean[0]; rec.mean[1] = mean[1]; rec.mean[2] = mean[2];
+  for (int k = 0; k < 6; k++) rec.icov[k] = 0.f;
+  bool valid = false;
+  if (cnt >= min_points) {
+    const double sq[9] = {q[0], q[1], q[2], q[1], q[3], q[4], q[2], q[4], q[5]};
+    double cov[9];
+    const double f = (np - 1.0) / np;
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) cov[a * 3 + b] = ((sq[a * 3 + b] - 2.0 * (s[a] * mean[b])) / np + mean[a] * mean[b]) * f;
+    double ev[3], V[9];
+    sym_eig3_d(cov, ev, V);
+    if (!(ev[0] < 0 || ev[1] < 0 || ev[2] <= 0)) {
+      const double min_ev = eig_mult * ev[2];
+      if (ev[0] < min_ev) {
+        ev[0] = min_ev;
+        if (ev[1] < min_ev) ev[1] = min_ev;
+        double Vi[9], VD[9];
+        inv3_d(V, Vi);
+        for (int rr = 0; rr < 3; rr++)
+          for (int c = 0; c < 3; c++) VD[rr * 3 + c] = V[rr * 3 + c] * ev[c];
+        for (int rr = 0; rr < 3; rr++)
+          for (int c = 0; c < 3; c++) cov[rr * 3 + c] = VD[rr * 3 + 0] * Vi[0 * 3 + c] + VD[rr * 3 + 1] * Vi[1 * 3 + c] + VD[rr * 3 + 2] * Vi[2 * 3 + c];
+      }
+      double icov[9];
+      inv3_d(cov, icov);
+      valid = true;
+      for (int k = 0; k < 9; k++)
+        if (isinf(icov[k])) valid = false;
+      if (valid) {
+        rec.icov[0] = (float)icov[0]; rec.icov[1] = (float)icov[1]; rec.icov[2] = (float)icov[2];
+        rec.icov[3] = (float)icov[4]; rec.icov[4] = (float)icov[5]; rec.icov[5] = (float)icov[8];
+        for (int k = 0; k < 9; k++) d[3 + k] = icov[k];
+      }
+    }
+  }
+  vox[r] = rec;
+  centroid[r] = make_float4(cf[0] / fn, cf[1] / fn, cf[2] / fn, valid ? 1.f : 0.f);
+  vvalid[r] = valid ? 1 : 0;
+  cell2vox[key] = valid ? r : -1;
+  if (valid) atomicAdd(&scalars[1], 1);
+}
+
+// ---- host driver -------------------------------------------------------------------------------------------
+int ndt_build_target(dgs_handle* h) {
+  const int64_t n = h->nt;
+  hipStream_t st = h->stream;
+  const float res = (float)h->prm.ndt_resolution;
+  h->grid = VoxelGrid{};
+  h->grid.leaf = res;
+  h->grid.inv_leaf = 1.0f / res;
+  h->grid_cells = 0;
+  h->counts_stale = true;
+  if (n == 0) return DGS_OK;
+
+  // 1. AABB
+  float hmm[6];
+  int slot = prof_begin(h, DGS_K_NDT_VOXEL_BUILD);
+  {
+    const int rc = cloud_minmax(h, h->target.ptr, n, hmm);
+    if (rc != DGS_OK) return rc;
+  }
+  if (!(hmm[0] <= hmm[3])) {  // no finite point
+    prof_end(h, DGS_K_NDT_VOXEL_BUILD, slot);
+    return DGS_OK;
+  }
+
+  // 2. grid extents (VoxelGridCovariance::applyFilter)
+  VoxelGrid& g = h->grid;
+  int64_t cells = 1;
+  for (int a = 0; a < 3; a++) {
+    g.min_b[a] = (int)std::floor(hmm[a] * g.inv_leaf);
+    g.max_b[a] = (int)std::floor(hmm[3 + a] * g.inv_leaf);
+    g.div_b[a] = g.max_b[a] - g.min_b[a] + 1;
+    const int64_t dx = (int64_t)((hmm[3 + a] - hmm[a]) * g.inv_leaf) + 1;
+    cells *= dx;
+  }
+  const int64_t dense_cells = (int64_t)g.div_b[0] * g.div_b[1] * g.div_b[2];
+  if (cells > INT32_MAX || dense_cells > INT32_MAX) {
+    prof_end(h, DGS_K_NDT_VOXEL_BUILD, slot);
+    h->err = "Leaf size is too small for the input dataset. Integer indices would overflow.";
+    return DGS_ERR_GRID_TOO_LARGE;
+  }
+  g.mul1 = g.div_b[0];
+  g.mul2 = g.div_b[0] * g.div_b[1];
+  h->grid_cells = dense_cells;
+
+  // 3. buffers
+  DGS_HIP_TRY(h, h->cell2vox.reserve((size_t)dense_cells));
+  DGS_HIP_TRY(h, h->key_in.reserve(n));
+  DGS_HIP_TRY(h, h->key_out.reserve(n));
+  DGS_HIP_TRY(h, h->val_in.reserve(n));
+  DGS_HIP_TRY(h, h->val_out.reserve(n));
+  DGS_HIP_TRY(h, h->run_keys.reserve(n));
+  DGS_HIP_TRY(h, h->run_counts.reserve(n));
+  DGS_HIP_TRY(h, h->run_offsets.reserve(n));
+  DGS_HIP_TRY(h, h->dev_scalars.reserve(8));
+  DGS_HIP_TRY(h, h->vox.reserve(n));
+  DGS_HIP_TRY(h, h->vox_centroid.reserve(n));
+  DGS_HIP_TRY(h, h->vox_dbg.reserve((size_t)n * 12));
+  DGS_HIP_TRY(h, h->vox_count.reserve(n));
+  DGS_HIP_TRY(h, h->vox_valid.reserve(n));
+  DGS_HIP_TRY(h, h->scratch_cloud.reserve(n));
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  int end_bit = 32;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0, end_bit, st);
+  (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, h->key_out.ptr, h->run_keys.ptr, h->run_counts.ptr, h->dev_scalars.ptr, (int)n, st);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t3, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st);
+  const size_t tmax = std::max(t1, std::max(t2, t3));
+  DGS_HIP_TRY(h, h->cub_temp.reserve(tmax + 256));
+
+  // 4. keys -> stable sort -> runs -> offsets
+  DGS_HIP_TRY(h, hipMemsetAsync(h->cell2vox.ptr, 0xFF, (size_t)dense_cells * sizeof(int), st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->dev_scalars.ptr, 0, 8 * sizeof(int), st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->run_counts.ptr, 0, (size_t)n * sizeof(int), st));
+  const int nb = (int)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, h->target.ptr, n, g, h->key_in.ptr, h->val_in.ptr);
+  size_t tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0,
+                                                    end_bit, st));
+  tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceRunLengthEncode::Encode(h->cub_temp.ptr, tb, h->key_out.ptr, h->run_keys.ptr, h->run_counts.ptr,
+                                                       h->dev_scalars.ptr, (int)n, st));
+  tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceScan::ExclusiveSum(h->cub_temp.ptr, tb, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st));
+  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(kBlock), 0, st, h->target.ptr, h->val_out.ptr, n, h->scratch_cloud.ptr);
+
+  // 5. per-voxel statistics
+  hipLaunchKernelGGL(voxel_finalize_kernel, dim3(nb), dim3(kBlock), 0, st, h->scratch_cloud.ptr, h->run_keys.ptr, h->run_counts.ptr,
+                     h->run_offsets.ptr, h->dev_scalars.ptr, h->prm.ndt_min_points_per_voxel, h->prm.ndt_min_covar_eigvalue_mult,
+                     h->cell2vox.ptr, h->vox.ptr, h->vox_centroid.ptr, h->vox_dbg.ptr, h->vox_count.ptr, h->vox_valid.ptr);
+  prof_end(h, DGS_K_NDT_VOXEL_BUILD, slot);
+  DGS_HIP_TRY(h, hipGetLastError());
+  g.cell2vox = h->cell2vox.ptr;
+  g.vox = h->vox.ptr;
+  g.centroid = h->vox_centroid.ptr;
+  return DGS_OK;
+}
+
+}  // namespace dgs

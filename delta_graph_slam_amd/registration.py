@@ -1,0 +1,271 @@
+"""Host-side mirror of the reference's registration objects, over the C ABI (include/dgs_reg.h).
+
+`Registration` keeps the pcl::Registration<PointXYZ,PointXYZ> method names the reference calls
+(/root/reference/apps/scan_matching_odometry_nodelet.cpp:180,185,218,222,228,318,327 and
+/root/reference/include/hdl_graph_slam/loop_detector.hpp:124,138,145,148,149,155), and
+`select_registration_method` mirrors the factory /root/reference/src/hdl_graph_slam/registrations.cpp:22-124
+(same `registration_method` strings, same `reg_*` parameter names and defaults).
+
+Clouds are float32 [N,4] arrays (numpy on the host, or torch tensors already resident in HBM); transforms
+are 4x4 float32 numpy arrays in ordinary row/column indexing (converted to Eigen's column-major at the ABI).
+There is no CPU fallback: constructing a Registration without the HIP library / a gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+
+try:  # torch is plumbing only: device memory + streams
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+__all__ = ["Registration", "select_registration_method", "DgsError"]
+DgsError = L.DgsError
+
+
+def _is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _cloud_ptr(cloud):
+    """-> (pointer, n, on_device, keepalive)"""
+    if _is_tensor(cloud):
+        if cloud.dtype != torch.float32 or cloud.dim() != 2 or cloud.shape[1] != 4:
+            raise ValueError("cloud tensors must be float32 [N,4]")
+        t = cloud.contiguous()
+        if t.is_cuda:
+            return C.c_void_p(t.data_ptr()), t.shape[0], 1, t
+        a = t.numpy()
+        return a.ctypes.data_as(C.c_void_p), a.shape[0], 0, a
+    a = np.ascontiguousarray(cloud, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("clouds must be float32 [N,4] (x, y, z, pad)")
+    return a.ctypes.data_as(C.c_void_p), a.shape[0], 0, a
+
+
+def _col16(T) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T.reshape(16))
+
+
+def _from_col16(t16) -> np.ndarray:
+    return np.array(t16, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class Registration:
+    """pcl::Registration-shaped object backed by one dgs_handle (HIP, gfx950)."""
+
+    def __init__(self, method: str = "NDT_OMP", device: int | None = None, **params):
+        lib = L.load()
+        self._lib = lib
+        m = L.METHOD_GICP if "GICP" in method else L.METHOD_NDT
+        p = L.Params()
+        rc = lib.dgs_params_init(C.byref(p), m)
+        if rc:
+            raise DgsError(rc, "dgs_params_init")
+        if device is not None:
+            p.device = int(device)
+        for k, v in params.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown registration parameter {k!r}")
+            setattr(p, k, v)
+        self.params = p
+        self.method = method
+        self._h = C.c_void_p()
+        rc = lib.dgs_create(C.byref(p), C.byref(self._h))
+        if rc:
+            raise DgsError(rc, "dgs_create failed (this package has no CPU fallback): " + (lib.dgs_last_error(None) or b"").decode())
+        self._converged = False
+        self._final = np.eye(4, dtype=np.float32)
+        self.last_result = None
+        self._keep = {}
+
+    # -- lifetime ---------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.dgs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise DgsError(rc, (self._lib.dgs_last_error(self._h) or b"").decode())
+
+    def set_stream(self, stream=None):
+        """Run on a torch.cuda.Stream (or the handle's own stream when None)."""
+        ptr = None if stream is None else C.c_void_p(stream.cuda_stream)
+        self._check(self._lib.dgs_set_stream(self._h, ptr))
+
+    def synchronize(self):
+        self._check(self._lib.dgs_synchronize(self._h))
+
+    # -- pcl::Registration surface ------------------------------------------------------------------------
+    def setInputTarget(self, cloud):
+        ptr, n, dev, keep = _cloud_ptr(cloud)
+        self._check(self._lib.dgs_set_input_target(self._h, ptr, n, dev))
+
+    def setInputSource(self, cloud):
+        ptr, n, dev, keep = _cloud_ptr(cloud)
+        self._n_source = n
+        self._check(self._lib.dgs_set_input_source(self._h, ptr, n, dev))
+
+    def align(self, guess=None, want_aligned: bool = False):
+        """align(*aligned, guess).  Returns the aligned cloud ([N,4] float32) when want_aligned, else None.
+        A failed registration never raises for numerical reasons: hasConverged() is False and the final
+        transformation is the guess (the contract at scan_matching_odometry_nodelet.cpp:222-226)."""
+        g = None if guess is None else _col16(guess)
+        gp = None if g is None else g.ctypes.data_as(C.c_void_p)
+        res = L.Result()
+        out = None
+        outp = None
+        if want_aligned:
+            out = np.empty((self._n_source, 4), dtype=np.float32)
+            outp = out.ctypes.data_as(C.c_void_p)
+        rc = self._lib.dgs_align(self._h, gp, C.byref(res), outp, 0)
+        self.last_result = res
+        self._converged = bool(res.converged)
+        self._final = _from_col16(res.final_transformation)
+        if rc in (L.DGS_OK,):
+            return out
+        if rc in (3, 4):  # PCL prints an error and returns; converged stays false
+            return None
+        self._check(rc)
+        return out
+
+    def hasConverged(self) -> bool:
+        return self._converged
+
+    def getFinalTransformation(self) -> np.ndarray:
+        return self._final.copy()
+
+    def getFitnessScore(self, max_range: float = 1.7976931348623157e308) -> float:
+        s = C.c_double(0)
+        self._check(self._lib.dgs_get_fitness_score(self._h, max_range, C.byref(s)))
+        return s.value
+
+    def getInlierFraction(self, max_sq_dist: float = 0.25) -> float:
+        """The nearestKSearch loop of publish_scan_matching_status (scan_matching_odometry_nodelet.cpp:321-332)."""
+        f = C.c_double(0)
+        self._check(self._lib.dgs_get_inlier_fraction(self._h, max_sq_dist, C.byref(f)))
+        return f.value
+
+    def nearestKSearch(self, queries):
+        """getSearchMethodTarget()->nearestKSearch(pt, 1, ...) for a batch of points -> (indices, sq_dists)."""
+        ptr, m, dev, keep = _cloud_ptr(queries)
+        if dev:
+            raise ValueError("host queries only in the Python mirror")
+        idx = np.empty(m, dtype=np.int32)
+        sq = np.empty(m, dtype=np.float32)
+        self._check(self._lib.dgs_nearest_search_target(self._h, ptr, m, 0, idx.ctypes.data_as(C.c_void_p), sq.ctypes.data_as(C.c_void_p)))
+        return idx, sq
+
+    # -- batched candidates (loop_detector.hpp:137-156) ----------------------------------------------------
+    def align_batch(self, sources, guesses=None, compute_fitness: bool = True, fitness_max_range: float = 1.7976931348623157e308):
+        n = len(sources)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)()
+        sizes = (C.c_int64 * n)()
+        keep = []
+        devs = set()
+        for i, s in enumerate(sources):
+            ptr, m, dev, k = _cloud_ptr(s)
+            ptrs[i] = ptr.value if ptr.value else 0
+            sizes[i] = m
+            keep.append(k)
+            if m:
+                devs.add(dev)
+        if len(devs) > 1:
+            raise ValueError("sources must be all host arrays or all device tensors")
+        on_device = devs.pop() if devs else 0
+        g = None
+        gp = None
+        if guesses is not None:
+            g = np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
+            gp = g.ctypes.data_as(C.c_void_p)
+        res = (L.Result * n)()
+        rc = self._lib.dgs_align_batch(self._h, n, ptrs, sizes, on_device, gp, 1 if compute_fitness else 0, fitness_max_range, res)
+        self._check(rc)
+        return [dict(T=_from_col16(r.final_transformation), converged=bool(r.converged), iterations=r.iterations,
+                     evaluations=r.evaluations, status=r.status, score=r.score, fitness=r.fitness) for r in res]
+
+    # -- measurement / test hooks ---------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.dgs_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self._lib.dgs_profile_reset(self._h))
+
+    def profile_get(self, kernel_id: int):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        self._check(self._lib.dgs_profile_get(self._h, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def counts(self):
+        out = (C.c_int64 * 8)()
+        self._check(self._lib.dgs_get_counts(self._h, out))
+        return dict(target_points=out[0], source_points=out[1], valid_voxels=out[2], occupied_voxels=out[3],
+                    grid_cells=out[4], evaluations=out[5])
+
+    def ndt_derivatives(self, p, T=None):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        t16 = None if T is None else _col16(T)
+        s = C.c_double(0)
+        g = np.zeros(6)
+        H = np.zeros((6, 6))
+        self._check(self._lib.dgs_ndt_derivatives(self._h, p.ctypes.data_as(C.c_void_p), None if t16 is None else t16.ctypes.data_as(C.c_void_p),
+                                                   C.byref(s), g.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
+        return s.value, g, H
+
+    def ndt_voxels(self):
+        n = C.c_int64(0)
+        self._check(self._lib.dgs_ndt_get_voxels(self._h, C.byref(n), None, None, None, None, None))
+        nv = n.value
+        keys = np.zeros(nv, np.int64)
+        counts = np.zeros(nv, np.int32)
+        valid = np.zeros(nv, np.int32)
+        mean = np.zeros((nv, 3))
+        icov = np.zeros((nv, 3, 3))
+        if nv:
+            self._check(self._lib.dgs_ndt_get_voxels(self._h, C.byref(n), keys.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                                      valid.ctypes.data_as(C.c_void_p), mean.ctypes.data_as(C.c_void_p),
+                                                      icov.ctypes.data_as(C.c_void_p)))
+        keep = keys >= 0
+        o = np.argsort(keys[keep])
+        return dict(keys=keys[keep][o], counts=counts[keep][o], valid=valid[keep][o].astype(bool), mean=mean[keep][o], icov=icov[keep][o])
+
+
+def select_registration_method(params: dict | None = None, device: int | None = None) -> Registration:
+    """Mirror of hdl_graph_slam::select_registration_method (registrations.cpp:22-124) for the HIP back-ends.
+
+    `params` plays the role of the private NodeHandle: keys are the reference's rosparam names
+    (registration_method, reg_num_threads, reg_transformation_epsilon, reg_maximum_iterations,
+    reg_max_correspondence_distance, reg_correspondence_randomness, reg_resolution, reg_nn_search_method).
+    "NDT_HIP" / "NDT_OMP" select NDT; "FAST_GICP_HIP" / "FAST_GICP" select GICP; unknown names warn and fall to NDT
+    exactly like registrations.cpp:88-91.
+    """
+    pr = dict(params or {})
+    method = pr.get("registration_method", "NDT_OMP")
+    common = dict(num_threads=int(pr.get("reg_num_threads", 0)),
+                  transformation_epsilon=float(pr.get("reg_transformation_epsilon", 0.01)),
+                  maximum_iterations=int(pr.get("reg_maximum_iterations", 64)))
+    if method in ("FAST_GICP", "FAST_GICP_HIP"):
+        return Registration("FAST_GICP", device=device,
+                            gicp_max_correspondence_distance=float(pr.get("reg_max_correspondence_distance", 2.5)),
+                            gicp_correspondence_randomness=int(pr.get("reg_correspondence_randomness", 20)), **common)
+    if "NDT" not in method:
+        import sys
+        print(f"warning: unknown registration type({method})\n       : use NDT", file=sys.stderr)
+    nn = pr.get("reg_nn_search_method", "DIRECT7")
+    search = L.NDT_SEARCH["KDTREE"] if nn == "KDTREE" else L.NDT_SEARCH["DIRECT1"] if nn == "DIRECT1" else L.NDT_SEARCH["DIRECT7"]
+    return Registration("NDT_OMP", device=device, ndt_resolution=float(pr.get("reg_resolution", 0.5)), ndt_search_method=search, **common)

@@ -1,0 +1,188 @@
+/* dgs_reg.h -- C ABI of libdgs_reg.so: MI355X (gfx950) scan registration for delta_graph_slam.
+ *
+ * This is the drop-in boundary for ONE hot path of KennyRotella/delta_graph_slam: the
+ * pcl::Registration<pcl::PointXYZ,pcl::PointXYZ> object that
+ *   /root/reference/src/hdl_graph_slam/registrations.cpp:22-124  (select_registration_method) builds, and that
+ *   /root/reference/apps/scan_matching_odometry_nodelet.cpp:173-270,309-346 and
+ *   /root/reference/include/hdl_graph_slam/loop_detector.hpp:119-173 drive.
+ * Each entry point names the reference interface it replaces.  The C++ adapter that re-exposes this ABI as a
+ * pcl::Registration subclass is include/dgs/hip_registration.hpp; INTEGRATION.md shows the factory patch.
+ *
+ * Conventions
+ *   - extern "C", opaque handle, POD structs, plain pointers + counts, int status (0 = DGS_OK), never throws.
+ *   - Clouds are pcl::PointXYZ arrays: float[n][4] = x, y, z, pad (16-byte stride; the pad value is ignored).
+ *   - Transforms are Eigen::Matrix4f memory: 16 floats, COLUMN-major.
+ *   - `on_device` != 0 means the pointer is a device (HBM) pointer valid on the handle's device; the call then
+ *     enqueues on the handle's stream and does not touch host memory.  With host pointers the library copies
+ *     at the call and never retains the pointer.
+ *   - A handle is used by one thread at a time; different handles are independent (two live handles per
+ *     process is the reference's normal case: odometry + loop detector).
+ *   - There is NO CPU fallback: every call fails with DGS_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef DGS_REG_H
+#define DGS_REG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGS_ABI_VERSION 1
+
+typedef struct dgs_handle dgs_handle;
+
+enum dgs_status {
+  DGS_OK = 0,
+  DGS_ERR_INVALID_ARGUMENT = 1,
+  DGS_ERR_HIP = 2,            /* a HIP runtime call failed; dgs_last_error() has the text */
+  DGS_ERR_NO_TARGET = 3,      /* align()/fitness before setInputTarget (PCL: "no input target dataset") */
+  DGS_ERR_NO_SOURCE = 4,
+  DGS_ERR_GRID_TOO_LARGE = 5, /* voxel index would overflow (pcl::VoxelGridCovariance: "Leaf size is too small") */
+  DGS_ERR_UNSUPPORTED = 6
+};
+
+/* registration_method strings of registrations.cpp:26-124 that this library serves */
+enum dgs_method {
+  DGS_METHOD_NDT = 0,  /* "NDT_OMP": pclomp::NormalDistributionsTransform, registrations.cpp:101-120 */
+  DGS_METHOD_GICP = 1  /* "FAST_GICP": fast_gicp::FastGICP, registrations.cpp:27-36 */
+};
+
+/* pclomp::NeighborSearchMethod (registrations.cpp:113-119), same enumerator order as upstream */
+enum dgs_ndt_search { DGS_NDT_KDTREE = 0, DGS_NDT_DIRECT26 = 1, DGS_NDT_DIRECT7 = 2, DGS_NDT_DIRECT1 = 3 };
+
+/* NDT step-length control (computeStepLengthMT).
+ * MORE_THUENTE (default): the More-Thuente line search as SURVEY.md App. A states it and PCL >= 1.8.1 executes it
+ *   (interval check `(step_max - step_min) < 0`).
+ * FIXED_STEP: the pre-1.8.1 PCL initialisation `(step_max - step_min) > 0`, which marks the interval converged at
+ *   once, so the trial loop never runs and every iteration is one derivative evaluation at the clamped Newton step.
+ *   Kept because un-pinned ndt_omp forks differ here; it oscillates on planar scenes (DESIGN.md "NDT sensitivity"). */
+enum dgs_ndt_line_search { DGS_NDT_LS_FIXED_STEP = 0, DGS_NDT_LS_MORE_THUENTE = 1 };
+
+/* fast_gicp::RegularizationMethod, same enumerator order as upstream */
+enum dgs_gicp_regularization {
+  DGS_GICP_REG_NONE = 0, DGS_GICP_REG_MIN_EIG = 1, DGS_GICP_REG_NORMALIZED_MIN_EIG = 2,
+  DGS_GICP_REG_PLANE = 3, DGS_GICP_REG_FROBENIUS = 4
+};
+enum dgs_gicp_optimizer { DGS_GICP_OPT_GAUSS_NEWTON = 0, DGS_GICP_OPT_LEVENBERG_MARQUARDT = 1 };
+
+typedef struct dgs_params {
+  uint32_t struct_size; /* sizeof(dgs_params), set by dgs_params_init */
+  int32_t method;       /* dgs_method */
+  int32_t device;       /* HIP device ordinal; -1 = the calling thread's current device */
+  int32_t num_threads;  /* reg_num_threads (registrations.cpp:30,102): accepted, ignored on the GPU */
+
+  /* setTransformationEpsilon / setMaximumIterations (registrations.cpp:31-32,110-111) */
+  double transformation_epsilon; /* default 0.01 */
+  int32_t maximum_iterations;    /* default 64 */
+
+  /* ---- NDT (pclomp::NormalDistributionsTransform) ---- */
+  int32_t ndt_search_method;        /* setNeighborhoodSearchMethod; default DGS_NDT_DIRECT7 (registrations.cpp:103) */
+  double ndt_resolution;            /* setResolution; factory default 0.5 (registrations.cpp:93) */
+  double ndt_step_size;             /* upstream default 0.1 */
+  double ndt_outlier_ratio;         /* upstream default 0.55 */
+  double ndt_min_covar_eigvalue_mult; /* VoxelGridCovariance default 0.01 */
+  int32_t ndt_min_points_per_voxel; /* VoxelGridCovariance default 6 */
+  int32_t ndt_line_search;          /* dgs_ndt_line_search, default DGS_NDT_LS_MORE_THUENTE */
+  int32_t ndt_mt_max_step_iterations; /* default 10 */
+  int32_t ndt_fix_hessian_d1;       /* 0 = upstream h_ang_d1 table (z-term +sy); 1 = exact (-sy) */
+
+  /* ---- GICP (fast_gicp::FastGICP) ---- */
+  double gicp_max_correspondence_distance; /* setMaxCorrespondenceDistance; factory default 2.5 (registrations.cpp:33) */
+  double gicp_rotation_epsilon;            /* upstream default 2e-3 */
+  double gicp_lm_init_lambda_factor;       /* upstream default 1e-9 */
+  int32_t gicp_correspondence_randomness;  /* setCorrespondenceRandomness (k), default 20 (registrations.cpp:34) */
+  int32_t gicp_regularization;             /* default DGS_GICP_REG_PLANE */
+  int32_t gicp_optimizer;                  /* default DGS_GICP_OPT_LEVENBERG_MARQUARDT */
+  int32_t gicp_lm_max_iterations;          /* default 10 */
+} dgs_params;
+
+/* What the callers read back after align(): hasConverged(), getFinalTransformation(), and the
+ * getFitnessScore() the loop detector takes per candidate (loop_detector.hpp:145-155). */
+typedef struct dgs_result {
+  float final_transformation[16]; /* getFinalTransformation(), column-major */
+  int32_t converged;              /* hasConverged() */
+  int32_t iterations;             /* nr_iterations_ */
+  int32_t evaluations;            /* derivative / linearisation passes executed */
+  int32_t status;                 /* dgs_status of this registration (batch entries fail independently) */
+  double score;                   /* NDT: score (trans_probability * Ns); GICP: final sum of Mahalanobis errors */
+  double fitness;                 /* getFitnessScore(max_range) when requested, else NaN */
+} dgs_result;
+
+/* Defaults = the reference factory's defaults for `method` (registrations.cpp:27-36 / 93-120). */
+int dgs_params_init(dgs_params* params, int32_t method);
+
+/* new pclomp::NormalDistributionsTransform / fast_gicp::FastGICP + setters (registrations.cpp:29-35,105-119) */
+int dgs_create(const dgs_params* params, dgs_handle** out);
+void dgs_destroy(dgs_handle* h);
+const char* dgs_last_error(const dgs_handle* h); /* never NULL; "" when the last call succeeded */
+int dgs_abi_version(void);
+
+/* Run all of this handle's work on a caller-owned hipStream_t (NULL = a stream the handle owns). */
+int dgs_set_stream(dgs_handle* h, void* hip_stream);
+/* Block until everything this handle enqueued has finished. */
+int dgs_synchronize(dgs_handle* h);
+
+/* registration->setInputTarget(cloud): scan_matching_odometry_nodelet.cpp:180,254; loop_detector.hpp:124.
+ * NDT: builds the voxel-Gaussian model (VoxelGridCovariance).  GICP: exact-NN index; covariances lazily. */
+int dgs_set_input_target(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_device);
+/* registration->setInputSource(cloud): scan_matching_odometry_nodelet.cpp:185; loop_detector.hpp:138 */
+int dgs_set_input_source(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_device);
+
+/* registration->align(*aligned, guess): scan_matching_odometry_nodelet.cpp:218; loop_detector.hpp:145.
+ * `guess16` NULL = identity.  `aligned_xyz16` (nullable) receives final_transformation * source,
+ * n_source points (host or device per `aligned_on_device`).  A registration that fails internally reports
+ * converged = 0 and final_transformation = guess (the reference treats that as "skip this frame",
+ * scan_matching_odometry_nodelet.cpp:222-226). */
+int dgs_align(dgs_handle* h, const float* guess16, dgs_result* out, float* aligned_xyz16, int32_t aligned_on_device);
+
+/* registration->getFitnessScore(max_range): loop_detector.hpp:148, scan_matching_odometry_nodelet.cpp:318.
+ * Mean squared exact-1-NN distance of final_transformation * source to the target over points with
+ * d^2 <= max_range (PCL compares the SQUARED distance with max_range; the reference's in-tree twin does the
+ * same, information_matrix_calculator.cpp:97); DBL_MAX when no point qualifies. */
+int dgs_get_fitness_score(dgs_handle* h, double max_range, double* score);
+
+/* The inlier loop of publish_scan_matching_status (scan_matching_odometry_nodelet.cpp:321-332):
+ * fraction of final_transformation * source points whose exact 1-NN squared distance to the target is
+ * < max_sq_dist (the reference passes 0.5 * 0.5). */
+int dgs_get_inlier_fraction(dgs_handle* h, double max_sq_dist, double* fraction);
+
+/* registration->getSearchMethodTarget()->nearestKSearch(pt, 1, idx, sqdist) for m query points
+ * (scan_matching_odometry_nodelet.cpp:327).  Exact; ties resolve to the lowest target index. */
+int dgs_nearest_search_target(dgs_handle* h, const float* queries_xyz16, int64_t m, int32_t on_device,
+                              int32_t* indices, float* sq_dists);
+
+/* The candidate loop of LoopDetector::matching (loop_detector.hpp:137-156) as ONE batched call against the
+ * current target: for c in [0, n): setInputSource(sources[c]); align(guess[c]); getFitnessScore(max_range).
+ * `sources[c]` / `sizes[c]` may be ragged; `guesses16` is n*16 floats (NULL = identity); fitness is computed
+ * when `compute_fitness` != 0.  results[c].status reports per-candidate failures.  The arg-min over
+ * (converged, fitness) stays with the caller (loop_detector.hpp:149-155). */
+int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const int64_t* sizes, int32_t on_device,
+                    const float* guesses16, int32_t compute_fitness, double fitness_max_range, dgs_result* results);
+
+/* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) ---------------------- */
+enum dgs_kernel_id {
+  DGS_K_NDT_DERIVATIVES = 0, DGS_K_NDT_SOLVE = 1, DGS_K_NDT_VOXEL_BUILD = 2, DGS_K_NN_SEARCH = 3,
+  DGS_K_GICP_LINEARIZE = 4, DGS_K_GICP_COVARIANCE = 5, DGS_K_TRANSFORM = 6, DGS_K_COUNT = 7
+};
+/* When enabled, every launch of a tracked kernel is bracketed by hipEvents on the launch stream. */
+int dgs_profile_enable(dgs_handle* h, int32_t enable);
+/* Sum of event-measured durations and number of launches since the last dgs_profile_reset (synchronises). */
+int dgs_profile_get(dgs_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches);
+int dgs_profile_reset(dgs_handle* h);
+/* Counts describing the current problem, for algorithmic-byte accounting:
+ * out[0] = target points, out[1] = source points, out[2] = valid voxels V, out[3] = occupied voxels,
+ * out[4] = voxel grid cells, out[5] = derivative evaluations of the last align / batch (sum over pairs). */
+int dgs_get_counts(dgs_handle* h, int64_t out[8]);
+
+/* Test hooks: single evaluations on the device, so tests can compare kernels with the oracle directly. */
+/* NDT computeDerivatives at pose p (6 doubles).  T16 NULL = build the float transform from p. */
+int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, double* score, double* grad6, double* hess36);
+/* NDT voxel table dump.  First call with NULL arrays returns the number of occupied voxels in *n. */
+int dgs_ndt_get_voxels(dgs_handle* h, int64_t* n, int64_t* keys, int32_t* counts, int32_t* valid, double* mean3,
+                       double* icov9);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGS_REG_H */

@@ -441,10 +441,10 @@ NdtResult NdtCpu::align(const float* guess, double* trajectory, int* traj_len) {
         double a_l = 0, a_u = 0;
         double f_l = psi_mt(a_l, phi_0, phi_0, d_phi_0, mu), g_l = dpsi_mt(d_phi_0, d_phi_0, mu);
         double f_u = psi_mt(a_u, phi_0, phi_0, d_phi_0, mu), g_u = dpsi_mt(d_phi_0, d_phi_0, mu);
-        // ndt_omp carries PCL <= 1.9's initialisation `(step_max - step_min) > 0`, which marks the interval
-        // converged whenever step_max > step_min, so the trial loop below never runs and every iteration costs
-        // one derivative evaluation (NDT_LS_NDT_OMP).  PCL >= 1.11 writes `< 0` (NDT_LS_MORE_THUENTE).
-        bool interval_converged = (prm.line_search == NDT_LS_NDT_OMP) ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
+        // PCL >= 1.8.1 (and SURVEY App. A) initialise with `(step_max - step_min) < 0` (NDT_LS_MORE_THUENTE); older PCL
+        // wrote `> 0`, which marks the interval converged whenever step_max > step_min so the trial loop below never
+        // runs and every iteration costs one evaluation at the clamped Newton step (NDT_LS_FIXED_STEP).
+        bool interval_converged = (prm.line_search == NDT_LS_FIXED_STEP) ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
         bool open_interval = true;
         a_t = step_init;
         a_t = std::min(a_t, step_max);

@@ -18,7 +18,7 @@
 namespace orc {
 
 enum NdtSearch { NDT_KDTREE = 0, NDT_DIRECT26 = 1, NDT_DIRECT7 = 2, NDT_DIRECT1 = 3 };  // pclomp enum order
-enum NdtLineSearch { NDT_LS_NDT_OMP = 0, NDT_LS_MORE_THUENTE = 1 };
+enum NdtLineSearch { NDT_LS_FIXED_STEP = 0, NDT_LS_MORE_THUENTE = 1 };
 
 struct NdtParams {
   double resolution = 1.0;               // pclomp default; reference sets reg_resolution (registrations.cpp:93,112)
@@ -29,7 +29,7 @@ struct NdtParams {
   int search_method = NDT_DIRECT7;       // registrations.cpp:103,113-119
   int min_points_per_voxel = 6;          // VoxelGridCovariance default
   double min_covar_eigvalue_mult = 0.01; // VoxelGridCovariance default
-  int line_search = NDT_LS_NDT_OMP;      // see ndt_cpu.cpp: computeStepLengthMT
+  int line_search = NDT_LS_MORE_THUENTE; // see ndt_cpu.cpp: computeStepLengthMT
   int mt_max_step_iterations = 10;
   int fix_hessian_d1 = 0;                // 0 = upstream table (h_ang_d1 z-term +sy), 1 = exact second derivative (-sy)
   int num_threads = 0;                   // registrations.cpp:102,106-108 (0 = all cores)

@@ -96,7 +96,7 @@ class NdtOracle:
     """CPU restatement of pclomp::NormalDistributionsTransform (registrations.cpp:101-120)."""
 
     def __init__(self, resolution=1.0, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
-                 step_size=0.1, outlier_ratio=0.55, line_search=0, num_threads=0, min_points_per_voxel=6,
+                 step_size=0.1, outlier_ratio=0.55, line_search=1, num_threads=0, min_points_per_voxel=6,
                  min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0):
         L = lib()
         p = NdtParams()

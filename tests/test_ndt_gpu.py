@@ -1,0 +1,162 @@
+"""-m gpu parity tests for the NDT hot path: HIP (through the C ABI) vs the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+from delta_graph_slam_amd import synth
+from tests.helpers import TOL_ROT, TOL_TRANS, f32_sqdist, f32_transform, pose_error
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg_cls():
+    from delta_graph_slam_amd.registration import Registration
+    return Registration
+
+
+def _pair(reg_cls, oracle_lib, tgt, src, **kw):
+    okw = dict(resolution=kw.get("ndt_resolution", 1.0), transformation_epsilon=kw.get("transformation_epsilon", 0.01),
+               search_method=kw.get("search", "DIRECT7"), line_search=kw.get("ndt_line_search", 1),
+               fix_hessian_d1=kw.get("ndt_fix_hessian_d1", 0), max_iterations=kw.get("maximum_iterations", 64))
+    o = oracle_lib.NdtOracle(**okw)
+    o.set_target(tgt)
+    o.set_source(src)
+    from delta_graph_slam_amd import _lib as L
+    gkw = {k: v for k, v in kw.items() if k != "search"}
+    gkw.setdefault("ndt_resolution", 1.0)
+    gkw["ndt_search_method"] = L.NDT_SEARCH[kw.get("search", "DIRECT7")]
+    r = reg_cls("NDT_OMP", **gkw)
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    return o, r
+
+
+def test_voxel_table_matches_oracle(reg_cls, oracle_lib):
+    tgt, src, _ = synth.planar_pair(n=16384)
+    o, r = _pair(reg_cls, oracle_lib, tgt, src)
+    vo, vg = o.voxels(), r.ndt_voxels()
+    assert np.array_equal(vo["keys"], vg["keys"])
+    assert np.array_equal(vo["counts"], vg["counts"])
+    assert np.array_equal(vo["valid"], vg["valid"])
+    # moments are accumulated in the same (point-index) order in double -> means are bit-identical
+    assert np.array_equal(vo["mean"], vg["mean"])
+    v = vo["valid"]
+    rel = np.abs(vo["icov"][v] - vg["icov"][v]).max() / np.abs(vo["icov"][v]).max()
+    assert rel < 1e-9
+    c = r.counts()
+    assert c["valid_voxels"] == v.sum() and c["occupied_voxels"] == len(vo["keys"])
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"])
+def test_derivatives_match_oracle(reg_cls, oracle_lib, search):
+    tgt, src, _ = synth.planar_pair(n=16384)
+    o, r = _pair(reg_cls, oracle_lib, tgt, src, search=search)
+    for p in ([0, 0, 0, 0, 0, 0], [0.2, -0.05, 0.03, 0.02, -0.03, 0.04], [0.3, -0.1, 0.05, 0.01, -0.02, 0.05]):
+        so, go, Ho = o.derivatives(np.array(p, float))
+        sg, gg, Hg = r.ndt_derivatives(np.array(p, float))
+        assert abs(so - sg) <= 2e-6 * abs(so)
+        # gradient / Hessian entries are sums with cancellation: compare against the largest entry
+        assert np.abs(go - gg).max() <= 1e-5 * np.abs(go).max() + 1e-9, (p, go, gg)
+        assert np.abs(Ho - Hg).max() <= 1e-5 * np.abs(Ho).max() + 1e-9, (p, np.abs(Ho - Hg).max() / np.abs(Ho).max())
+
+
+@pytest.mark.parametrize("line_search", [0, 1])
+def test_align_cfg1_matches_oracle(reg_cls, oracle_lib, line_search):
+    tgt, src, Tgt = synth.planar_pair()
+    o, r = _pair(reg_cls, oracle_lib, tgt, src, ndt_line_search=line_search)
+    ro = o.align()
+    r.align()
+    assert r.hasConverged() == ro["converged"]
+    assert r.last_result.iterations == ro["iterations"]
+    assert r.last_result.evaluations == ro["evaluations"]
+    dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+    assert dt <= TOL_TRANS and dr <= TOL_ROT, (dt, dr)
+    # and both are near the ground truth (sanity, not parity)
+    dt, dr = pose_error(r.getFinalTransformation(), Tgt)
+    assert dt < 0.02 and dr < 2e-3
+
+
+def test_align_tight_epsilon_same_fixed_point(reg_cls, oracle_lib):
+    tgt, src, _ = synth.planar_pair()
+    o, r = _pair(reg_cls, oracle_lib, tgt, src, transformation_epsilon=1e-6)
+    ro = o.align()
+    r.align()
+    dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+    assert dt <= TOL_TRANS and dr <= TOL_ROT, (dt, dr)
+
+
+def test_align_with_guess_and_aligned_cloud(reg_cls, oracle_lib):
+    tgt, src, Tgt = synth.planar_pair()
+    guess = synth.make_transform((0.25, -0.05, 0.0), (0.0, 0.0, 0.04)).astype(np.float32)
+    o, r = _pair(reg_cls, oracle_lib, tgt, src)
+    ro = o.align(guess)
+    aligned = r.align(guess, want_aligned=True)
+    dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+    assert dt <= TOL_TRANS and dr <= TOL_ROT, (dt, dr)
+    ref = f32_transform(r.getFinalTransformation(), src)
+    assert np.abs(aligned[:, :3] - ref).max() < 1e-4
+    assert np.all(aligned[:, 3] == 1.0)
+
+
+def test_fitness_and_nn_exact(reg_cls, oracle_lib):
+    from scipy.spatial import cKDTree
+    tgt, src, _ = synth.planar_pair(n=8192)
+    o, r = _pair(reg_cls, oracle_lib, tgt, src)
+    r.align()
+    T = r.getFinalTransformation()
+    xt = f32_transform(T, src)
+    tree = cKDTree(tgt[:, :3].astype(np.float64))
+    _, nn = tree.query(xt.astype(np.float64), k=1)
+    d2 = f32_sqdist(xt, tgt[nn, :3])
+    # exact search: float distances to the GPU's answer can only be <= the kd-tree's (ties/rounding), never larger
+    q = np.ones((xt.shape[0], 4), np.float32)
+    q[:, :3] = xt
+    idx, sq = r.nearestKSearch(q)
+    d2_gpu_idx = f32_sqdist(xt, tgt[idx, :3])
+    assert np.array_equal(sq, d2_gpu_idx)          # reported distance is the float distance to the reported index
+    assert np.all(sq <= d2)                         # exactness
+    assert (idx != nn).mean() < 1e-3                # differences only on float ties
+    fit = r.getFitnessScore()
+    assert abs(fit - float(np.mean(sq.astype(np.float64)))) <= 1e-12 * fit
+    mr = 0.05
+    fit_r = r.getFitnessScore(mr)
+    sel = sq <= np.float32(mr)
+    assert abs(fit_r - float(np.mean(sq[sel].astype(np.float64)))) <= 1e-12 * fit_r
+    assert r.getFitnessScore(-1.0) == 1.7976931348623157e308   # DBL_MAX when nothing qualifies
+    inl = r.getInlierFraction(0.25)
+    assert abs(inl - float((sq < np.float32(0.25)).mean())) < 1e-12
+
+
+def test_batch_matches_single(reg_cls, oracle_lib):
+    tgt, src, _ = synth.planar_pair(n=8192)
+    rng = np.random.default_rng(3)
+    sources, guesses = [], []
+    for k in range(5):
+        n = int(rng.integers(3000, 8192))
+        sources.append(src[:n].copy())
+        guesses.append(synth.make_transform((0.3 + rng.uniform(-0.1, 0.1), -0.1 + rng.uniform(-0.1, 0.1), 0.0), (0, 0, 0.05 + rng.uniform(-0.02, 0.02))).astype(np.float32))
+    sources.append(np.zeros((0, 4), np.float32))   # ragged edge: empty candidate
+    guesses.append(np.eye(4, dtype=np.float32))
+    o, r = _pair(reg_cls, oracle_lib, tgt, src)
+    res = r.align_batch(sources, guesses, compute_fitness=True)
+    assert res[-1]["status"] == 4 and not res[-1]["converged"]
+    for k in range(5):
+        r.setInputSource(sources[k])
+        r.align(guesses[k])
+        assert np.array_equal(res[k]["T"], r.getFinalTransformation())   # bit-identical: same kernels, same order
+        assert res[k]["converged"] == r.hasConverged()
+        assert res[k]["fitness"] == r.getFitnessScore()
+        o.set_source(sources[k])
+        ro = o.align(guesses[k])
+        dt, dr = pose_error(res[k]["T"], ro["T"])
+        assert dt <= TOL_TRANS and dr <= TOL_ROT, (k, dt, dr)
+        assert res[k]["iterations"] == ro["iterations"]
+
+
+def test_errors_surface_as_not_converged(reg_cls):
+    r = reg_cls("NDT_OMP", ndt_resolution=1.0)
+    assert r.align() is None and not r.hasConverged()       # no target: PCL prints an error and returns
+    tgt, src, _ = synth.planar_pair(n=2048)
+    r.setInputTarget(tgt)
+    assert r.align() is None and not r.hasConverged()       # no source
+    assert np.array_equal(r.getFinalTransformation(), np.eye(4, dtype=np.float32))
