@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- scan registrations/sec on 64k-pt KITTI-shaped pairs (BASELINE.json metric), MI355X.
+
+One "step" = one LoopDetector.matching() pass (/root/reference/include/hdl_graph_slam/loop_detector.hpp:119-173)
+over a batch of candidate registrations per GPU: setInputTarget(new keyframe) once, then for each of P candidate
+65,536-point HDL-64E-shaped source scans: setInputSource, align(yaw/xy guess), getFitnessScore; then the arg-min.
+Every pair is the BASELINE configs[1] workload (NDT, 1.0 m resolution, DIRECT7, 64 max iterations); P pairs per GPU
+is the per-GPU shard of configs[3] (256 candidates over 8 GPUs = 32).  All clouds are resident in HBM before the
+timed region.  Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL), candidates sharded with no
+data-path collective except the all_gather of result records; weak scaling (P per GPU fixed).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def pose_error(Ta, Tb):
+    Ta = np.asarray(Ta, np.float64)
+    Tb = np.asarray(Tb, np.float64)
+    dt = np.linalg.norm(Ta[:3, 3] - Tb[:3, 3])
+    R = Ta[:3, :3].T @ Tb[:3, :3]
+    w = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return dt, float(np.arctan2(np.linalg.norm(w), 0.5 * (np.trace(R) - 1.0)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=32, help="candidate registrations per GPU per step")
+    ap.add_argument("--points", type=int, default=65536)
+    ap.add_argument("--distinct-scans", type=int, default=8, help="distinct ray-cast source scans per GPU (re-used round-robin)")
+    ap.add_argument("--resolution", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget of the cpu_baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd import synth
+    from delta_graph_slam_amd.loop_detector import KeyFrame, LoopDetector
+    from delta_graph_slam_amd.registration import Registration
+
+    P = args.pairs
+    # ---- synthetic workload (seeded; rank-specific scans), uploaded to HBM before timing
+    tgt, sources, guesses, gts = synth.loop_batch(n_candidates=P, n_points=args.points, seed=40 + 1000 * rank,
+                                                 distinct_scans=min(args.distinct_scans, P))
+    dev = torch.device("cuda", local_rank)
+    new_kf = KeyFrame(cloud=torch.from_numpy(tgt).to(dev), estimate=np.eye(3), accum_distance=100.0, id=0)
+    cands = []
+    for c in range(P):
+        G = guesses[c]
+        est = np.eye(3)
+        est[:2, :2] = G[:2, :2]
+        est[:2, 2] = G[:2, 3]
+        cands.append(KeyFrame(cloud=torch.from_numpy(sources[c]).to(dev), estimate=est, accum_distance=0.0, id=c + 1))
+
+    reg = Registration("NDT_OMP", device=local_rank, ndt_resolution=args.resolution, ndt_search_method=L.NDT_SEARCH["DIRECT7"],
+                       transformation_epsilon=0.01, maximum_iterations=64)
+    det = LoopDetector({"fitness_score_thresh": 1e9}, registration=reg)
+
+    # the detector shards candidates[rank::world]; give every rank its own P candidates by offering a world*P list
+    # whose rank-th stride is this rank's data (other entries are never touched by this rank)
+    def step():
+        if world == 1:
+            return det.matching(cands, new_kf)
+        full = [None] * (world * P)
+        full[rank::world] = cands
+        # only this rank's entries are dereferenced by register_shard
+        return det.matching(_Sparse(full, cands[0]), new_kf)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    evals = 0
+    for _ in range(args.steps):
+        step()
+        evals += reg.counts()["evaluations"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    regs = world * P * args.steps
+    value = regs / dt
+    records = det.last_records
+
+    out = {
+        "metric": "scan registrations/sec (64k-pt pairs)", "value": value, "unit": "registrations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 per-point, f64 accumulate", "data": "synthetic",
+        "config": {"workload": "cfg2 KITTI HDL-64E-shaped pairs (65,536 pts after voxel filter), NDT res %.1f m DIRECT7, eps 0.01, "
+                               "max 64 iterations; %d candidate pairs per GPU per step against one target (LoopDetector::matching, "
+                               "cfg4 shard), fitness score per candidate, inputs resident in HBM" % (args.resolution, P),
+                   "pairs_per_gpu": P, "points_per_scan": args.points, "parallelism": "candidates sharded one process per GPU, all_gather of result records"},
+    }
+
+    if rank == 0:
+        cnt = reg.counts()
+        Ns, Nt, V = args.points, cnt["target_points"], cnt["valid_voxels"]
+        out["ms_per_iter"] = 1e3 * dt / max(evals, 1) * P   # wall ms per derivative evaluation of one pair stream (P run concurrently)
+        out["evaluations_per_registration"] = evals / (P * args.steps)
+        conv = float(np.mean(records[:, 1] > 0.5)) if records is not None else None
+        out["converged_fraction"] = conv
+
+        # ---- roofline leg: same steps with every ndt_derivatives launch bracketed by HIP events on its stream
+        reg.profile_enable(True)
+        reg.profile_reset()
+        ev2 = 0
+        for _ in range(args.steps):
+            step()
+            ev2 += reg.counts()["evaluations"]
+        ms, launches = reg.profile_get(L.K_NDT_DERIVATIVES)
+        ms_solve, l_solve = reg.profile_get(L.K_NDT_SOLVE)
+        ms_nn, l_nn = reg.profile_get(L.K_NN_SEARCH)
+        ms_vox, l_vox = reg.profile_get(L.K_NDT_VOXEL_BUILD)
+        reg.profile_enable(False)
+        bytes_per_eval = 16 * Ns + 48 * V + 344            # stream source once, table once, 43 doubles out
+        total_bytes = ev2 * bytes_per_eval
+        achieved = total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "ndt_derivatives_kernel<DIRECT7>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
+                           "algorithmic_bytes_per_launch": total_bytes / max(launches, 1),
+                           "bytes_per_evaluation": bytes_per_eval, "valid_voxels": V,
+                           "other_kernels_ms_per_step": {"ndt_solve": ms_solve / args.steps, "nn_fitness": ms_nn / args.steps,
+                                                         "voxel_build": ms_vox / args.steps, "ndt_derivatives": ms / args.steps}}
+
+        # ---- CPU baseline + pose RMSE: the oracle (C++/OpenMP restatement) on a bounded sample of the same candidates
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            ncpu = orc.max_threads()
+
+            def cpu_run(threads, budget, perturbed=False, limit=P):
+                o = orc.NdtOracle(resolution=args.resolution, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
+                                  num_threads=threads, perturbed=perturbed)
+                tc0 = time.perf_counter()
+                o.set_target(tgt)
+                Ts, t_first = [], None
+                while len(Ts) < limit:
+                    c = len(Ts)
+                    o.set_source(sources[c])
+                    Ts.append(o.align(guesses[c])["T"])
+                    if t_first is None:
+                        t_first = time.perf_counter() - tc0
+                    if len(Ts) >= 2 and (time.perf_counter() - tc0) + t_first > budget:
+                        break
+                return Ts, time.perf_counter() - tc0
+
+            # all host cores (the reference's reg_num_threads=0 default), and a 16-thread run in case the box over-subscribes
+            T_all, t_all = cpu_run(ncpu, args.cpu_seconds)
+            T_16, t_16 = cpu_run(min(16, ncpu), args.cpu_seconds / 3, limit=len(T_all))
+            rate_all, rate_16 = len(T_all) / t_all, len(T_16) / t_16
+            best_rate, best_cores, best_n, best_t = (rate_all, ncpu, len(T_all), t_all) if rate_all >= rate_16 else (rate_16, min(16, ncpu), len(T_16), t_16)
+            out["cpu_baseline"] = {"value": best_rate, "unit": "registrations/s", "cores": best_cores, "kind": "port",
+                                   "sample": "%d of the %d candidate pairs of one step (setInputTarget + align each; getFitnessScore not included), "
+                                             "oracle C++/OpenMP restatement, %.1f s; %d threads: %.2f/s, %d threads: %.2f/s"
+                                             % (best_n, P, best_t, ncpu, rate_all, min(16, ncpu), rate_16)}
+            out["speedup_vs_cpu_baseline"] = value / best_rate
+            # parity: GPU vs oracle, beside the oracle's own numerical band (same source, FMA contraction on)
+            T_fma, _ = cpu_run(ncpu, args.cpu_seconds, perturbed=True, limit=len(T_all))
+            n_cmp = min(len(T_all), len(T_fma))
+            eg = np.array([pose_error(records[c, 4:20].reshape(4, 4), T_all[c]) for c in range(n_cmp)])
+            eb = np.array([pose_error(T_fma[c], T_all[c]) for c in range(n_cmp)])
+            well = (eb[:, 0] <= 1e-4) & (eb[:, 1] <= 1e-5)
+
+            def rms(a):
+                return float(np.sqrt(np.mean(np.square(a)))) if len(a) else None
+
+            out["pose_rmse_vs_oracle"] = {
+                "pairs": int(n_cmp), "translation_m": rms(eg[:, 0]), "rotation_rad": rms(eg[:, 1]),
+                "max_translation_m": float(eg[:, 0].max()), "max_rotation_rad": float(eg[:, 1].max()),
+                "well_conditioned_pairs": int(well.sum()),
+                "well_conditioned_translation_m": rms(eg[well, 0]), "well_conditioned_rotation_rad": rms(eg[well, 1]),
+                "well_conditioned_max_translation_m": float(eg[well, 0].max()) if well.any() else None,
+                "well_conditioned_max_rotation_rad": float(eg[well, 1].max()) if well.any() else None,
+                "oracle_self_band_translation_m": rms(eb[:, 0]), "oracle_self_band_rotation_rad": rms(eb[:, 1]),
+                "note": "well-conditioned = pairs on which the oracle and its FMA-contracted twin agree to 1e-4 m / 1e-5 rad"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _Sparse(list):
+    """A candidate list in which only this rank's stride is populated (len() is the global candidate count)."""
+
+    def __init__(self, items, filler):
+        super().__init__(items)
+        self._filler = filler
+
+    def __getitem__(self, i):
+        v = super().__getitem__(i)
+        return self._filler if v is None else v
+
+
+if __name__ == "__main__":
+    main()

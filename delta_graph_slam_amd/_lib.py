@@ -47,6 +47,7 @@ SYMBOLS = [
     "dgs_synchronize", "dgs_set_input_target", "dgs_set_input_source", "dgs_align", "dgs_get_fitness_score",
     "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_align_batch", "dgs_profile_enable",
     "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_get_voxels",
+    "dgs_ndt_get_trajectory",
 ]
 
 _lib = None
@@ -85,5 +86,6 @@ def load():
     lib.dgs_get_counts.argtypes = [C.c_void_p, P(C.c_int64)]
     lib.dgs_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_double), C.c_void_p, C.c_void_p]
     lib.dgs_ndt_get_voxels.argtypes = [C.c_void_p, P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dgs_ndt_get_trajectory.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, P(C.c_int32)]
     _lib = lib
     return lib

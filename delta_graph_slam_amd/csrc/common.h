@@ -15,6 +15,7 @@ constexpr int kBlock = 256;        // 4 waves per workgroup: one wave per SIMD
 constexpr int kAccum = 28;         // score + 6 gradient + 21 upper-triangle Hessian terms
 constexpr int kAccumPad = 32;      // partial-sum row stride (doubles)
 constexpr int kMaxPartialBlocks = 1024;  // per pair
+constexpr int kTrajCap = 72;
 
 // ---- NDT voxel-Gaussian target model in HBM ------------------------------------------------------------
 // One 48-byte record per occupied voxel (three 16-byte loads): the mean stays double because upstream forms
@@ -73,6 +74,9 @@ struct NdtPair {
   double a_t, a_l, f_l, g_l, a_u, f_u, g_u;
   double step_init;
   float final_T[16];   // column-major, = final_transformation_
+  int traj_len;        // test hook: pose after every outer iteration (first kTrajCap entries)
+  int pad1;
+  double traj[kTrajCap][6];
 };
 
 struct NdtConsts {

@@ -457,6 +457,17 @@ int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, doubl
   return ndt_probe(h, p6, T16, score, grad6, hess36);
 }
 
+int dgs_ndt_get_trajectory(dgs_handle* h, int32_t pair, double* poses6, int32_t* len) {
+  if (!h || !poses6 || !len || pair < 0) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (h->prm.method != DGS_METHOD_NDT || (size_t)pair >= h->pairs.cap) return DGS_ERR_UNSUPPORTED;
+  int n = 0;
+  int rc = ndt_trajectory(h, pair, poses6, &n);
+  *len = n;
+  return rc;
+}
+
 int dgs_ndt_get_voxels(dgs_handle* h, int64_t* n, int64_t* keys, int32_t* counts, int32_t* valid, double* mean3, double* icov9) {
   if (!h || !n) return DGS_ERR_INVALID_ARGUMENT;
   h->err.clear();

@@ -102,6 +102,7 @@ int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]);
 // ndt_align.hip
 int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs_host, const int* sizes_host,
                     const float* guesses16, dgs_result* results);
+int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len);
 int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36);
 // nn_bvh.hip
 int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n);

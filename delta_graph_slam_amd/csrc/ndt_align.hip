@@ -282,11 +282,16 @@ __device__ void svd_solve6_dev(const double* A, const double* b, double* x) {
 // float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap)
 __device__ void write_evaluation(NdtPair& st, const NdtConsts& c, const double* x, int need_hessian, bool write_T) {
   if (write_T) {
+    // Eigen builds Translation * AngleAxis(x) * AngleAxis(y) * AngleAxis(z) in float.  One ulp of a rotation entry moves
+    // a point at 50 m by 3 um, which the q = x' - mean cancellation turns into ~1e-4 of that point's contribution, so
+    // the entries are formed reproducibly: trig of the FLOAT angle evaluated in double and rounded once (what a
+    // correctly rounded cosf/sinf returns), products individually rounded in the source order of the expression.
     const float rx = (float)x[3], ry = (float)x[4], rz = (float)x[5];
-    const float cx = cosf(rx), sx = sinf(rx), cy = cosf(ry), sy = sinf(ry), cz = cosf(rz), sz = sinf(rz);
-    const float r00 = cy * cz, r01 = -cy * sz, r02 = sy;
-    const float r10 = cx * sz + sx * sy * cz, r11 = cx * cz - sx * sy * sz, r12 = -sx * cy;
-    const float r20 = sx * sz - cx * sy * cz, r21 = sx * cz + cx * sy * sz, r22 = cx * cy;
+    const float cx = (float)cos((double)rx), sx = (float)sin((double)rx), cy = (float)cos((double)ry), sy = (float)sin((double)ry),
+                cz = (float)cos((double)rz), sz = (float)sin((double)rz);
+    const float r00 = mul_rn(cy, cz), r01 = mul_rn(-cy, sz), r02 = sy;
+    const float r10 = add_rn(mul_rn(cx, sz), mul_rn(mul_rn(sx, sy), cz)), r11 = sub_rn(mul_rn(cx, cz), mul_rn(mul_rn(sx, sy), sz)), r12 = mul_rn(-sx, cy);
+    const float r20 = sub_rn(mul_rn(sx, sz), mul_rn(mul_rn(cx, sy), cz)), r21 = add_rn(mul_rn(sx, cz), mul_rn(mul_rn(cx, sy), sz)), r22 = mul_rn(cx, cy);
     const float t0 = (float)x[0], t1 = (float)x[1], t2 = (float)x[2];
     st.T[0] = r00; st.T[1] = r01; st.T[2] = r02; st.T[3] = t0;
     st.T[4] = r10; st.T[5] = r11; st.T[6] = r12; st.T[7] = t1;
@@ -431,6 +436,10 @@ __device__ bool begin_iteration(NdtPair& st, const NdtConsts& c) {
 __device__ bool end_iteration(NdtPair& st, const NdtConsts& c) {
   const double a = st.a_t;
   for (int k = 0; k < 6; k++) st.p[k] += st.dir[k] * a;
+  if (st.traj_len < kTrajCap) {
+    for (int k = 0; k < 6; k++) st.traj[st.traj_len][k] = st.p[k];
+  }
+  st.traj_len++;
   bool conv = false;
   if (st.nr_iterations > c.max_iterations || (st.nr_iterations && (fabs(a) < c.trans_eps))) conv = true;
   st.nr_iterations++;
@@ -572,6 +581,8 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   st.T[8] = G[2]; st.T[9] = G[6]; st.T[10] = G[10]; st.T[11] = G[14];
   for (int k = 0; k < 16; k++) st.final_T[k] = G[k];
   st.phase = probe ? PH_PROBE : PH_INIT_EVAL;
+  for (int k = 0; k < 6; k++) st.traj[0][k] = in.p0[k];
+  st.traj_len = 1;
   st.active = 1;
   st.nr_iterations = 0;
   st.evaluations = 0;
@@ -795,6 +806,19 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   return DGS_OK;
 }
 
+// Test hook: poses after every outer iteration of pair `pair` of the last align / batch.
+int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len) {
+  std::vector<char> buf(sizeof(NdtPair));
+  DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  DGS_HIP_TRY(h, hipMemcpy(buf.data(), h->pairs.ptr + pair, sizeof(NdtPair), hipMemcpyDeviceToHost));
+  const NdtPair* st = reinterpret_cast<const NdtPair*>(buf.data());
+  const int n = std::min(st->traj_len, kTrajCap);
+  for (int i = 0; i < n; i++)
+    for (int k = 0; k < 6; k++) out[i * 6 + k] = st->traj[i][k];
+  *len = n;
+  return DGS_OK;
+}
+
 // Test hook: one computeDerivatives evaluation on the device.
 int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36) {
   hipStream_t st = h->stream;
@@ -806,10 +830,16 @@ int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, 
     std::memcpy(T, T16, sizeof(T));
   } else {  // pose_to_matrix in float, as the solver builds it
     const float rx = (float)p6[3], ry = (float)p6[4], rz = (float)p6[5];
-    const float cx = std::cos(rx), sx = std::sin(rx), cy = std::cos(ry), sy = std::sin(ry), cz = std::cos(rz), sz = std::sin(rz);
-    T[0] = cy * cz; T[4] = -cy * sz; T[8] = sy; T[12] = (float)p6[0];
-    T[1] = cx * sz + sx * sy * cz; T[5] = cx * cz - sx * sy * sz; T[9] = -sx * cy; T[13] = (float)p6[1];
-    T[2] = sx * sz - cx * sy * cz; T[6] = sx * cz + cx * sy * sz; T[10] = cx * cy; T[14] = (float)p6[2];
+    const float cx = (float)std::cos((double)rx), sx = (float)std::sin((double)rx), cy = (float)std::cos((double)ry), sy = (float)std::sin((double)ry),
+                cz = (float)std::cos((double)rz), sz = (float)std::sin((double)rz);
+    auto mul = [](float a, float b) { volatile float r = a * b; return (float)r; };  // keep host products un-fused
+    T[0] = mul(cy, cz); T[4] = mul(-cy, sz); T[8] = sy; T[12] = (float)p6[0];
+    { volatile float a = mul(cx, sz), b = mul(mul(sx, sy), cz); T[1] = a + b; }
+    { volatile float a = mul(cx, cz), b = mul(mul(sx, sy), sz); T[5] = a - b; }
+    T[9] = mul(-sx, cy); T[13] = (float)p6[1];
+    { volatile float a = mul(sx, sz), b = mul(mul(cx, sy), cz); T[2] = a - b; }
+    { volatile float a = mul(sx, cz), b = mul(mul(cx, sy), sz); T[6] = a + b; }
+    T[10] = mul(cx, cy); T[14] = (float)p6[2];
     T[3] = T[7] = T[11] = 0.f; T[15] = 1.f;
   }
   int rc = ndt_setup(h, 1, &src, &n, T, p6, &bpp);

@@ -1,0 +1,170 @@
+"""Loop-closure candidate matching: the reference's LoopDetector over the HIP registration, sharded across GPUs.
+
+Mirrors /root/reference/include/hdl_graph_slam/loop_detector.hpp:
+  LoopDetector(pnh)          :41-51   parameter names and defaults
+  detect                     :59-70
+  find_candidates            :83-111
+  matching                   :119-173  setInputTarget once, then per candidate setInputSource / align(guess) /
+                                       getFitnessScore(fitness_score_max_range); keep arg-min over converged candidates
+                                       (a candidate is skipped iff !converged or score > best, so on an exact tie the
+                                       LATER candidate wins, :149); accept iff best <= fitness_score_thresh (:162).
+
+MI355X mapping: the candidate loop has no cross-iteration dependency, so candidates are dealt
+round-robin to the ranks of a torch.distributed group (one process per GPU; backend "nccl" is RCCL over xGMI), each
+rank registers its shard as ONE batched launch sequence (Registration.align_batch), and the only exchange step is an
+all_gather of fixed-size result records; the arg-min then runs in ORIGINAL candidate order on every rank, which
+reproduces the reference's sequential tie-breaking exactly.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, List, Optional, Sequence
+
+import numpy as np
+
+from .transforms import transform2Dto3D, transform3Dto2D
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    torch = None
+    dist = None
+
+__all__ = ["KeyFrame", "Loop", "LoopDetector", "RECORD_WIDTH"]
+
+DBL_MAX = 1.7976931348623157e308
+RECORD_WIDTH = 20  # candidate index, converged, fitness, status, 16 x transform (row-major)
+
+
+@dataclass
+class KeyFrame:
+    """The fields of hdl_graph_slam::KeyFrame the loop detector reads (keyframe.hpp:25-59)."""
+    cloud: Any                      # float32 [N,4] (numpy or HBM-resident torch tensor)
+    estimate: np.ndarray            # node->estimate(): 3x3 SE2 matrix (Eigen::Isometry2d)
+    accum_distance: float = 0.0
+    id: int = -1
+
+
+@dataclass
+class Loop:
+    """loop_detector.hpp:16-28"""
+    key1: KeyFrame
+    key2: KeyFrame
+    relative_pose: np.ndarray       # 4x4 float32
+    relative_pose2D: np.ndarray     # 3x3 float32
+    score: float = field(default=0.0)
+
+
+class LoopDetector:
+    def __init__(self, params: Optional[dict] = None, registration=None, group=None, device: Optional[int] = None):
+        pr = dict(params or {})
+        self.distance_thresh = float(pr.get("distance_thresh", 5.0))
+        self.accum_distance_thresh = float(pr.get("accum_distance_thresh", 8.0))
+        self.distance_from_last_edge_thresh = float(pr.get("min_edge_interval", 5.0))
+        self.fitness_score_max_range = float(pr.get("fitness_score_max_range", DBL_MAX))
+        self.fitness_score_thresh = float(pr.get("fitness_score_thresh", 0.5))
+        if registration is None:
+            from .registration import select_registration_method
+            registration = select_registration_method(pr, device=device)
+        self.registration = registration
+        self.last_edge_accum_distance = 0.0
+        self.group = group
+        self.last_records = None
+
+    # ---------------------------------------------------------------------------------------------- reference logic
+    def detect(self, keyframes: Sequence[KeyFrame], new_keyframes: Sequence[KeyFrame]) -> List[Loop]:
+        loops = []
+        for nk in new_keyframes:
+            cands = self.find_candidates(keyframes, nk)
+            loop = self.matching(cands, nk)
+            if loop is not None:
+                loops.append(loop)
+        return loops
+
+    def find_candidates(self, keyframes: Sequence[KeyFrame], new_keyframe: KeyFrame) -> List[KeyFrame]:
+        if new_keyframe.accum_distance - self.last_edge_accum_distance < self.distance_from_last_edge_thresh:
+            return []
+        out = []
+        p2 = np.asarray(new_keyframe.estimate, np.float64)[:2, 2]
+        for k in keyframes:
+            if new_keyframe.accum_distance - k.accum_distance < self.accum_distance_thresh:
+                continue
+            p1 = np.asarray(k.estimate, np.float64)[:2, 2]
+            if np.linalg.norm(p1 - p2) > self.distance_thresh:
+                continue
+            out.append(k)
+        return out
+
+    @staticmethod
+    def guess_for(new_keyframe: KeyFrame, candidate: KeyFrame) -> np.ndarray:
+        """loop_detector.hpp:139-143"""
+        rel = np.linalg.inv(np.asarray(new_keyframe.estimate, np.float64)) @ np.asarray(candidate.estimate, np.float64)
+        return transform2Dto3D(rel.astype(np.float32))
+
+    # ---------------------------------------------------------------------------------------------- sharding
+    def _world(self):
+        if dist is not None and dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.group), dist.get_world_size(self.group)
+        return 0, 1
+
+    def register_shard(self, candidates: Sequence[KeyFrame], new_keyframe: KeyFrame) -> np.ndarray:
+        """Registers this rank's share (candidates[rank::world]) against the new keyframe and returns the
+        gathered [n_candidates, RECORD_WIDTH] float64 records in original candidate order."""
+        rank, world = self._world()
+        n = len(candidates)
+        self.registration.setInputTarget(new_keyframe.cloud)
+        mine = list(range(rank, n, world))
+        sources = [candidates[c].cloud for c in mine]
+        guesses = [self.guess_for(new_keyframe, candidates[c]) for c in mine]
+        results = self.registration.align_batch(sources, guesses, compute_fitness=True,
+                                                fitness_max_range=self.fitness_score_max_range) if mine else []
+        per_rank = (n + world - 1) // world
+        rec = np.full((per_rank, RECORD_WIDTH), -1.0, dtype=np.float64)
+        for j, (c, r) in enumerate(zip(mine, results)):
+            rec[j, 0] = c
+            rec[j, 1] = 1.0 if r["converged"] else 0.0
+            rec[j, 2] = r["fitness"]
+            rec[j, 3] = r.get("status", 0)
+            rec[j, 4:20] = np.asarray(r["T"], np.float64).reshape(16)
+        if world == 1:
+            allrec = rec
+        else:
+            backend = dist.get_backend(self.group)
+            dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+            local = torch.from_numpy(rec).to(dev)
+            gathered = torch.empty((world * per_rank, RECORD_WIDTH), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(gathered, local, group=self.group)   # the path's one exchange step
+            allrec = gathered.cpu().numpy()
+        out = np.full((n, RECORD_WIDTH), -1.0, dtype=np.float64)
+        for row in allrec:
+            c = int(row[0])
+            if 0 <= c < n:
+                out[c] = row
+        self.last_records = out
+        return out
+
+    @staticmethod
+    def select_best(records: np.ndarray):
+        """The arg-min of loop_detector.hpp:126-156 over gathered records, in candidate order."""
+        best_score = DBL_MAX
+        best = -1
+        for c in range(records.shape[0]):
+            converged = records[c, 1] > 0.5
+            score = records[c, 2]
+            if (not converged) or score > best_score:
+                continue
+            best_score = score
+            best = c
+        return best, best_score
+
+    def matching(self, candidates: Sequence[KeyFrame], new_keyframe: KeyFrame) -> Optional[Loop]:
+        if len(candidates) == 0:
+            return None
+        records = self.register_shard(candidates, new_keyframe)
+        best, best_score = self.select_best(records)
+        if best < 0 or best_score > self.fitness_score_thresh:
+            return None   # "loop not found..."
+        rel = records[best, 4:20].reshape(4, 4).astype(np.float32)
+        self.last_edge_accum_distance = new_keyframe.accum_distance
+        return Loop(new_keyframe, candidates[best], rel, transform3Dto2D(rel), best_score)

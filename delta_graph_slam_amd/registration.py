@@ -227,6 +227,12 @@ class Registration:
                                                    C.byref(s), g.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
         return s.value, g, H
 
+    def ndt_trajectory(self, pair: int = 0):
+        buf = np.zeros((72, 6))
+        n = C.c_int32(0)
+        self._check(self._lib.dgs_ndt_get_trajectory(self._h, pair, buf.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return buf[:n.value].copy()
+
     def ndt_voxels(self):
         n = C.c_int64(0)
         self._check(self._lib.dgs_ndt_get_voxels(self._h, C.byref(n), None, None, None, None, None))

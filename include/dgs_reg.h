@@ -178,6 +178,9 @@ int dgs_get_counts(dgs_handle* h, int64_t out[8]);
 /* Test hooks: single evaluations on the device, so tests can compare kernels with the oracle directly. */
 /* NDT computeDerivatives at pose p (6 doubles).  T16 NULL = build the float transform from p. */
 int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, double* score, double* grad6, double* hess36);
+/* NDT pose (x, y, z, rx, ry, rz) after every outer iteration of pair `pair` of the last align / align_batch;
+ * poses6 holds up to 72 x 6 doubles, *len receives the number written (entry 0 is the initial guess). */
+int dgs_ndt_get_trajectory(dgs_handle* h, int32_t pair, double* poses6, int32_t* len);
 /* NDT voxel table dump.  First call with NULL arrays returns the number of occupied voxels in *n. */
 int dgs_ndt_get_voxels(dgs_handle* h, int64_t* n, int64_t* keys, int32_t* counts, int32_t* valid, double* mean3,
                        double* icov9);

@@ -38,7 +38,11 @@ void euler_angles_012(const float* T, float res[3]) {
 // (Translation<float,3>(p0,p1,p2) * AngleAxis<float>(p3,X) * AngleAxis<float>(p4,Y) * AngleAxis<float>(p5,Z)).matrix()
 void pose_to_matrix_f32(const double p[6], float* T) {
   const float rx = static_cast<float>(p[3]), ry = static_cast<float>(p[4]), rz = static_cast<float>(p[5]);
-  const float cx = std::cos(rx), sx = std::sin(rx), cy = std::cos(ry), sy = std::sin(ry), cz = std::cos(rz), sz = std::sin(rz);
+  // Eigen evaluates std::cos(float); a correctly rounded cosf equals the double cosine rounded once, which is what is
+  // written here so that the value does not depend on the libm at hand (differs from glibc cosf in ~1e-7 of arguments).
+  const float cx = static_cast<float>(std::cos(static_cast<double>(rx))), sx = static_cast<float>(std::sin(static_cast<double>(rx)));
+  const float cy = static_cast<float>(std::cos(static_cast<double>(ry))), sy = static_cast<float>(std::sin(static_cast<double>(ry)));
+  const float cz = static_cast<float>(std::cos(static_cast<double>(rz))), sz = static_cast<float>(std::sin(static_cast<double>(rz)));
   // R = Rx * Ry * Rz
   const float r00 = cy * cz, r01 = -cy * sz, r02 = sy;
   const float r10 = cx * sz + sx * sy * cz, r11 = cx * cz - sx * sy * sz, r12 = -sx * cy;

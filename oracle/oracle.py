@@ -23,12 +23,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_LIB_FMA_PATH = os.path.join(_HERE, "_build", "liboracle_fma.so")  # same source, FMA contraction on (perturbed build)
 
 
 def build(force: bool = False) -> str:
     """Compile the C++ restatement with g++ (see oracle/Makefile)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    if force or not (os.path.exists(_LIB_PATH) and os.path.exists(_LIB_FMA_PATH)):
+        subprocess.check_call(["make", "-C", _HERE, "all"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
@@ -52,23 +53,25 @@ class Result(C.Structure):
                 ("evaluations", C.c_int32), ("pad", C.c_int32), ("score", C.c_double)]
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(perturbed: bool = False):
+    """The restatement (perturbed=False) or its FMA-contracted twin (perturbed=True)."""
+    if perturbed not in _libs:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.orc_ndt_create.restype = C.c_void_p
-        _lib.orc_ndt_derivatives.restype = C.c_double
-        _lib.orc_ndt_voxels.restype = C.c_int64
-        if hasattr(_lib, "orc_gicp_create"):
-            _lib.orc_gicp_create.restype = C.c_void_p
-            _lib.orc_fitness_score.restype = C.c_double
-            _lib.orc_gicp_linearize.restype = C.c_double
-            _lib.orc_gicp_compute_error.restype = C.c_double
-    return _lib
+        L = C.CDLL(_LIB_FMA_PATH if perturbed else _LIB_PATH)
+        L.orc_ndt_create.restype = C.c_void_p
+        L.orc_ndt_derivatives.restype = C.c_double
+        L.orc_ndt_voxels.restype = C.c_int64
+        if hasattr(L, "orc_gicp_create"):
+            L.orc_gicp_create.restype = C.c_void_p
+            L.orc_gicp_linearize.restype = C.c_double
+            L.orc_gicp_compute_error.restype = C.c_double
+        if hasattr(L, "orc_fitness_score"):
+            L.orc_fitness_score.restype = C.c_double
+        _libs[perturbed] = L
+    return _libs[perturbed]
 
 
 SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
@@ -97,8 +100,9 @@ class NdtOracle:
 
     def __init__(self, resolution=1.0, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
                  step_size=0.1, outlier_ratio=0.55, line_search=1, num_threads=0, min_points_per_voxel=6,
-                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0):
-        L = lib()
+                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False):
+        L = lib(perturbed)
+        self._L = L
         p = NdtParams()
         L.orc_ndt_default_params(C.byref(p))
         p.resolution = resolution
@@ -119,26 +123,26 @@ class NdtOracle:
 
     def __del__(self):
         try:
-            lib().orc_ndt_destroy(self._h)
+            self._L.orc_ndt_destroy(self._h)
         except Exception:
             pass
 
     def set_target(self, cloud):
         a, pa = _f32c(cloud)
         assert a.ndim == 2 and a.shape[1] == 4
-        lib().orc_ndt_set_target(self._h, pa, C.c_int64(a.shape[0]))
+        self._L.orc_ndt_set_target(self._h, pa, C.c_int64(a.shape[0]))
 
     def set_source(self, cloud):
         a, pa = _f32c(cloud)
         assert a.ndim == 2 and a.shape[1] == 4
-        lib().orc_ndt_set_source(self._h, pa, C.c_int64(a.shape[0]))
+        self._L.orc_ndt_set_source(self._h, pa, C.c_int64(a.shape[0]))
 
     def align(self, guess=None):
         g = _colmajor16(np.eye(4) if guess is None else guess)
         res = Result()
         traj = np.zeros((self.max_iterations + 4, 6))
         tl = C.c_int32(0)
-        lib().orc_ndt_align(self._h, g.ctypes.data_as(C.POINTER(C.c_float)), C.byref(res),
+        self._L.orc_ndt_align(self._h, g.ctypes.data_as(C.POINTER(C.c_float)), C.byref(res),
                             traj.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tl))
         return dict(T=_from_colmajor16(res.T), converged=bool(res.converged), iterations=res.iterations,
                     evaluations=res.evaluations, score=res.score, trajectory=traj[:tl.value].copy())
@@ -151,12 +155,12 @@ class NdtOracle:
         if T is not None:
             t16 = _colmajor16(T)
             Tp = t16.ctypes.data_as(C.POINTER(C.c_float))
-        s = lib().orc_ndt_derivatives(self._h, pp, Tp, g.ctypes.data_as(C.POINTER(C.c_double)),
+        s = self._L.orc_ndt_derivatives(self._h, pp, Tp, g.ctypes.data_as(C.POINTER(C.c_double)),
                                       H.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(1 if compute_hessian else 0))
         return s, g, H
 
     def voxels(self):
-        L = lib()
+        L = self._L
         n = L.orc_ndt_voxels(self._h, None, None, None, None, None, None)
         keys = np.zeros(n, np.int64)
         counts = np.zeros(n, np.int32)
@@ -174,7 +178,7 @@ class NdtOracle:
         mn = (C.c_int32 * 3)()
         mx = (C.c_int32 * 3)()
         dv = (C.c_int32 * 3)()
-        lib().orc_ndt_grid(self._h, mn, mx, dv)
+        self._L.orc_ndt_grid(self._h, mn, mx, dv)
         return np.array(mn), np.array(mx), np.array(dv)
 
 
