@@ -48,14 +48,9 @@ enum NdtPhase : int {
   PH_DONE = 5
 };
 
-struct NdtPair {
-  // -- read by the derivative kernel
-  float T[12];         // row-major 3x4 float transform of this evaluation
-  float jang[8][3];    // eq. 6.19 tables (float, from double trig)
-  float hang[15][3];   // eq. 6.21 tables
-  int need_hessian;
-  int active;          // 0: every kernel returns immediately for this pair
-  // -- optimiser state (solve kernel, lane 0)
+// Optimiser state proper: the solve kernel copies it into registers, advances it with every lane of one wave computing
+// the same values, and lane 0 writes it back.
+struct NdtSolver {
   int phase;
   int nr_iterations;
   int evaluations;
@@ -63,7 +58,7 @@ struct NdtPair {
   int step_iterations;
   int interval_converged;
   int open_interval;
-  int pad0;
+  int traj_len;        // test hook: pose after every outer iteration (first kTrajCap entries)
   double p[6];         // current pose (x, y, z, rx, ry, rz)
   double x_t[6];       // pose of the evaluation in flight
   double dir[6];       // unit Newton direction (possibly reversed)
@@ -73,9 +68,17 @@ struct NdtPair {
   double phi_0, d_phi_0;
   double a_t, a_l, f_l, g_l, a_u, f_u, g_u;
   double step_init;
+};
+
+struct NdtPair {
+  // -- read by the derivative kernel
+  float T[12];         // row-major 3x4 float transform of this evaluation
+  float jang[8][3];    // eq. 6.19 tables (float, from double trig)
+  float hang[15][3];   // eq. 6.21 tables
+  int need_hessian;
+  int active;          // 0: every kernel returns immediately for this pair
+  NdtSolver s;
   float final_T[16];   // column-major, = final_transformation_
-  int traj_len;        // test hook: pose after every outer iteration (first kTrajCap entries)
-  int pad1;
   double traj[kTrajCap][6];
 };
 

@@ -194,51 +194,45 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
   }
 }
 
-// ================================================================================================ solver (lane 0)
-// Gaussian elimination with full pivoting on a 6x6; returns the smallest/largest |pivot| ratio in *rcond.
-__device__ void lu_solve6(const double* Ain, const double* b, double* x, double* rcond) {
-  double A[36], y[6];
-  int cp[6];
-  for (int i = 0; i < 36; i++) A[i] = Ain[i];
-  for (int i = 0; i < 6; i++) { y[i] = b[i]; cp[i] = i; }
-  double pmax = 0, pmin = DBL_MAX;
+// ================================================================================================ solver
+// 6x6 solve by Gauss-Jordan elimination with row pivoting, one matrix element per lane (lanes 0..41 hold [A | b]);
+// every value that steers control flow is wave-uniform.  *rcond receives min|pivot| / max|pivot|.
+__device__ void gj_solve6_wave(const double* A, const double* b, double* x, double* rcond) {
+  const int lane = threadIdx.x & 63;
+  const int i = (lane < 42) ? lane / 7 : 0, j = (lane < 42) ? lane % 7 : 0;
+  double a = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c < 7; c++)
+      if (lane == r * 7 + c) a = (c < 6) ? A[r * 6 + c] : b[r];
+  double pmax = 0.0, pmin = DBL_MAX;
+#pragma unroll
   for (int k = 0; k < 6; k++) {
-    int pr = k, pc = k;
-    double best = -1;
-    for (int i = k; i < 6; i++)
-      for (int j = k; j < 6; j++)
-        if (fabs(A[i * 6 + j]) > best) { best = fabs(A[i * 6 + j]); pr = i; pc = j; }
-    if (pr != k) {
-      for (int j = 0; j < 6; j++) { const double t = A[k * 6 + j]; A[k * 6 + j] = A[pr * 6 + j]; A[pr * 6 + j] = t; }
-      const double t = y[k]; y[k] = y[pr]; y[pr] = t;
+    int best_r = k;
+    double best_v = -1.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double v = fabs(__shfl(a, r * 7 + k, 64));
+      if (r >= k && v > best_v) { best_v = v; best_r = r; }
     }
-    if (pc != k) {
-      for (int i = 0; i < 6; i++) { const double t = A[i * 6 + k]; A[i * 6 + k] = A[i * 6 + pc]; A[i * 6 + pc] = t; }
-      const int t = cp[k]; cp[k] = cp[pc]; cp[pc] = t;
-    }
-    const double piv = A[k * 6 + k];
+    const int src = (i == k) ? best_r * 7 + j : ((i == best_r) ? k * 7 + j : lane);
+    a = __shfl(a, src, 64);
+    const double piv = __shfl(a, k * 7 + k, 64);
     pmax = fmax(pmax, fabs(piv));
     pmin = fmin(pmin, fabs(piv));
-    if (piv == 0.0) continue;
-    for (int i = k + 1; i < 6; i++) {
-      const double l = A[i * 6 + k] / piv;
-      for (int j = k + 1; j < 6; j++) A[i * 6 + j] -= l * A[k * 6 + j];
-      y[i] -= l * y[k];
-    }
+    const double rowk = __shfl(a, k * 7 + j, 64);
+    const double colk = __shfl(a, i * 7 + k, 64);
+    if (piv != 0.0) a = (i == k) ? a / piv : a - colk * (rowk / piv);
   }
+#pragma unroll
+  for (int r = 0; r < 6; r++) x[r] = __shfl(a, r * 7 + 6, 64);
   *rcond = (pmax > 0) ? pmin / pmax : 0.0;
-  double z[6];
-  for (int i = 5; i >= 0; i--) {
-    double s = y[i];
-    for (int j = i + 1; j < 6; j++) s -= A[i * 6 + j] * z[j];
-    z[i] = (A[i * 6 + i] != 0.0) ? s / A[i * 6 + i] : 0.0;
-  }
-  for (int i = 0; i < 6; i++) x[cp[i]] = z[i];
 }
 
 // Pseudo-inverse solve through a one-sided Jacobi SVD with Eigen::JacobiSVD's default rank threshold
 // (6 * eps * s_max).  Slow path: only taken when the elimination above meets a (numerically) singular Hessian.
-__device__ void svd_solve6_dev(const double* A, const double* b, double* x) {
+__device__ __noinline__ void svd_solve6_dev(const double* A, const double* b, double* x) {
   double U[36], V[36];
   for (int i = 0; i < 36; i++) { U[i] = A[i]; V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
   for (int sweep = 0; sweep < 40; sweep++) {
@@ -279,8 +273,9 @@ __device__ void svd_solve6_dev(const double* A, const double* b, double* x) {
   }
 }
 
-// float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap)
-__device__ void write_evaluation(NdtPair& st, const NdtConsts& c, const double* x, int need_hessian, bool write_T) {
+// float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap),
+// written to the pair's HBM record by lane 0 (`writer`); every lane computes the same values.
+__device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, const double* x, int need_hessian, bool write_T, bool writer) {
   if (write_T) {
     // Eigen builds Translation * AngleAxis(x) * AngleAxis(y) * AngleAxis(z) in float.  One ulp of a rotation entry moves
     // a point at 50 m by 3 um, which the q = x' - mean cancellation turns into ~1e-4 of that point's contribution, so
@@ -293,47 +288,52 @@ __device__ void write_evaluation(NdtPair& st, const NdtConsts& c, const double* 
     const float r10 = add_rn(mul_rn(cx, sz), mul_rn(mul_rn(sx, sy), cz)), r11 = sub_rn(mul_rn(cx, cz), mul_rn(mul_rn(sx, sy), sz)), r12 = mul_rn(-sx, cy);
     const float r20 = sub_rn(mul_rn(sx, sz), mul_rn(mul_rn(cx, sy), cz)), r21 = add_rn(mul_rn(sx, cz), mul_rn(mul_rn(cx, sy), sz)), r22 = mul_rn(cx, cy);
     const float t0 = (float)x[0], t1 = (float)x[1], t2 = (float)x[2];
-    st.T[0] = r00; st.T[1] = r01; st.T[2] = r02; st.T[3] = t0;
-    st.T[4] = r10; st.T[5] = r11; st.T[6] = r12; st.T[7] = t1;
-    st.T[8] = r20; st.T[9] = r21; st.T[10] = r22; st.T[11] = t2;
-    float* F = st.final_T;  // column-major
-    F[0] = r00; F[1] = r10; F[2] = r20; F[3] = 0.f;
-    F[4] = r01; F[5] = r11; F[6] = r21; F[7] = 0.f;
-    F[8] = r02; F[9] = r12; F[10] = r22; F[11] = 0.f;
-    F[12] = t0; F[13] = t1; F[14] = t2; F[15] = 1.f;
+    if (writer) {
+      st->T[0] = r00; st->T[1] = r01; st->T[2] = r02; st->T[3] = t0;
+      st->T[4] = r10; st->T[5] = r11; st->T[6] = r12; st->T[7] = t1;
+      st->T[8] = r20; st->T[9] = r21; st->T[10] = r22; st->T[11] = t2;
+      float* F = st->final_T;  // column-major
+      F[0] = r00; F[1] = r10; F[2] = r20; F[3] = 0.f;
+      F[4] = r01; F[5] = r11; F[6] = r21; F[7] = 0.f;
+      F[8] = r02; F[9] = r12; F[10] = r22; F[11] = 0.f;
+      F[12] = t0; F[13] = t1; F[14] = t2; F[15] = 1.f;
+    }
   }
   double cx, cy, cz, sx, sy, sz;
   if (fabs(x[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(x[3]); sx = sin(x[3]); }
   if (fabs(x[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(x[4]); sy = sin(x[4]); }
   if (fabs(x[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(x[5]); sz = sin(x[5]); }
-  float (*J)[3] = st.jang;
-  J[0][0] = (float)(-sx * sz + cx * sy * cz); J[0][1] = (float)(-sx * cz - cx * sy * sz); J[0][2] = (float)(-cx * cy);
-  J[1][0] = (float)(cx * sz + sx * sy * cz);  J[1][1] = (float)(cx * cz - sx * sy * sz);  J[1][2] = (float)(-sx * cy);
-  J[2][0] = (float)(-sy * cz);                J[2][1] = (float)(sy * sz);                 J[2][2] = (float)(cy);
-  J[3][0] = (float)(sx * cy * cz);            J[3][1] = (float)(-sx * cy * sz);           J[3][2] = (float)(sx * sy);
-  J[4][0] = (float)(-cx * cy * cz);           J[4][1] = (float)(cx * cy * sz);            J[4][2] = (float)(-cx * sy);
-  J[5][0] = (float)(-cy * sz);                J[5][1] = (float)(-cy * cz);                J[5][2] = 0.f;
-  J[6][0] = (float)(cx * cz - sx * sy * sz);  J[6][1] = (float)(-cx * sz - sx * sy * cz); J[6][2] = 0.f;
-  J[7][0] = (float)(sx * cz + cx * sy * sz);  J[7][1] = (float)(cx * sy * cz - sx * sz);  J[7][2] = 0.f;
-  float (*H)[3] = st.hang;
-  H[0][0] = (float)(-cx * sz - sx * sy * cz); H[0][1] = (float)(-cx * cz + sx * sy * sz); H[0][2] = (float)(sx * cy);    // a2
-  H[1][0] = (float)(-sx * sz + cx * sy * cz); H[1][1] = (float)(-cx * sy * sz - sx * cz); H[1][2] = (float)(-cx * cy);   // a3
-  H[2][0] = (float)(cx * cy * cz);            H[2][1] = (float)(-cx * cy * sz);           H[2][2] = (float)(cx * sy);    // b2
-  H[3][0] = (float)(sx * cy * cz);            H[3][1] = (float)(-sx * cy * sz);           H[3][2] = (float)(sx * sy);    // b3
-  H[4][0] = (float)(-sx * cz - cx * sy * sz); H[4][1] = (float)(sx * sz - cx * sy * cz);  H[4][2] = 0.f;                 // c2
-  H[5][0] = (float)(cx * cz - sx * sy * sz);  H[5][1] = (float)(-sx * sy * cz - cx * sz); H[5][2] = 0.f;                 // c3
-  // d1: upstream PCL / ndt_omp carry +sy in the z slot; the exact second derivative is -sy (dgs_params.ndt_fix_hessian_d1)
-  H[6][0] = (float)(-cy * cz);                H[6][1] = (float)(cy * sz);                 H[6][2] = (float)(c.fix_hessian_d1 ? -sy : sy);
-  H[7][0] = (float)(-sx * sy * cz);           H[7][1] = (float)(sx * sy * sz);            H[7][2] = (float)(sx * cy);    // d2
-  H[8][0] = (float)(cx * sy * cz);            H[8][1] = (float)(-cx * sy * sz);           H[8][2] = (float)(-cx * cy);   // d3
-  H[9][0] = (float)(sy * sz);                 H[9][1] = (float)(sy * cz);                 H[9][2] = 0.f;                 // e1
-  H[10][0] = (float)(-sx * cy * sz);          H[10][1] = (float)(-sx * cy * cz);          H[10][2] = 0.f;                // e2
-  H[11][0] = (float)(cx * cy * sz);           H[11][1] = (float)(cx * cy * cz);           H[11][2] = 0.f;                // e3
-  H[12][0] = (float)(-cy * cz);               H[12][1] = (float)(cy * sz);                H[12][2] = 0.f;                // f1
-  H[13][0] = (float)(-cx * sz - sx * sy * cz); H[13][1] = (float)(-cx * cz + sx * sy * sz); H[13][2] = 0.f;              // f2
-  H[14][0] = (float)(-sx * sz + cx * sy * cz); H[14][1] = (float)(-cx * sy * sz - sx * cz); H[14][2] = 0.f;              // f3
-  for (int k = 0; k < 6; k++) st.x_t[k] = x[k];
-  st.need_hessian = need_hessian;
+  if (writer) {
+    float (*J)[3] = st->jang;
+    J[0][0] = (float)(-sx * sz + cx * sy * cz); J[0][1] = (float)(-sx * cz - cx * sy * sz); J[0][2] = (float)(-cx * cy);
+    J[1][0] = (float)(cx * sz + sx * sy * cz);  J[1][1] = (float)(cx * cz - sx * sy * sz);  J[1][2] = (float)(-sx * cy);
+    J[2][0] = (float)(-sy * cz);                J[2][1] = (float)(sy * sz);                 J[2][2] = (float)(cy);
+    J[3][0] = (float)(sx * cy * cz);            J[3][1] = (float)(-sx * cy * sz);           J[3][2] = (float)(sx * sy);
+    J[4][0] = (float)(-cx * cy * cz);           J[4][1] = (float)(cx * cy * sz);            J[4][2] = (float)(-cx * sy);
+    J[5][0] = (float)(-cy * sz);                J[5][1] = (float)(-cy * cz);                J[5][2] = 0.f;
+    J[6][0] = (float)(cx * cz - sx * sy * sz);  J[6][1] = (float)(-cx * sz - sx * sy * cz); J[6][2] = 0.f;
+    J[7][0] = (float)(sx * cz + cx * sy * sz);  J[7][1] = (float)(cx * sy * cz - sx * sz);  J[7][2] = 0.f;
+    float (*H)[3] = st->hang;
+    H[0][0] = (float)(-cx * sz - sx * sy * cz); H[0][1] = (float)(-cx * cz + sx * sy * sz); H[0][2] = (float)(sx * cy);    // a2
+    H[1][0] = (float)(-sx * sz + cx * sy * cz); H[1][1] = (float)(-cx * sy * sz - sx * cz); H[1][2] = (float)(-cx * cy);   // a3
+    H[2][0] = (float)(cx * cy * cz);            H[2][1] = (float)(-cx * cy * sz);           H[2][2] = (float)(cx * sy);    // b2
+    H[3][0] = (float)(sx * cy * cz);            H[3][1] = (float)(-sx * cy * sz);           H[3][2] = (float)(sx * sy);    // b3
+    H[4][0] = (float)(-sx * cz - cx * sy * sz); H[4][1] = (float)(sx * sz - cx * sy * cz);  H[4][2] = 0.f;                 // c2
+    H[5][0] = (float)(cx * cz - sx * sy * sz);  H[5][1] = (float)(-sx * sy * cz - cx * sz); H[5][2] = 0.f;                 // c3
+    // d1: upstream PCL / ndt_omp carry +sy in the z slot; the exact second derivative is -sy (dgs_params.ndt_fix_hessian_d1)
+    H[6][0] = (float)(-cy * cz);                H[6][1] = (float)(cy * sz);                 H[6][2] = (float)(c.fix_hessian_d1 ? -sy : sy);
+    H[7][0] = (float)(-sx * sy * cz);           H[7][1] = (float)(sx * sy * sz);            H[7][2] = (float)(sx * cy);    // d2
+    H[8][0] = (float)(cx * sy * cz);            H[8][1] = (float)(-cx * sy * sz);           H[8][2] = (float)(-cx * cy);   // d3
+    H[9][0] = (float)(sy * sz);                 H[9][1] = (float)(sy * cz);                 H[9][2] = 0.f;                 // e1
+    H[10][0] = (float)(-sx * cy * sz);          H[10][1] = (float)(-sx * cy * cz);          H[10][2] = 0.f;                // e2
+    H[11][0] = (float)(cx * cy * sz);           H[11][1] = (float)(cx * cy * cz);           H[11][2] = 0.f;                // e3
+    H[12][0] = (float)(-cy * cz);               H[12][1] = (float)(cy * sz);                H[12][2] = 0.f;                // f1
+    H[13][0] = (float)(-cx * sz - sx * sy * cz); H[13][1] = (float)(-cx * cz + sx * sy * sz); H[13][2] = 0.f;              // f2
+    H[14][0] = (float)(-sx * sz + cx * sy * cz); H[14][1] = (float)(-cx * sy * sz - sx * cz); H[14][2] = 0.f;              // f3
+    st->need_hessian = need_hessian;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) s.x_t[k] = x[k];
 }
 
 // ---- More-Thuente helpers (More & Thuente 1994; Sun & Yuan 2006 eq. 2.4.x) ---------------------------------
@@ -388,122 +388,132 @@ __device__ inline double dot6(const double* a, const double* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
 
-// Starts one outer iteration from (score, grad, hess) at st.p.  Returns true when an evaluation was queued,
+// Starts one outer iteration from (score, grad, hess) at s.p.  Returns true when an evaluation was queued,
 // false when the iteration finished without one (zero step) or the registration ended.
-__device__ bool begin_iteration(NdtPair& st, const NdtConsts& c) {
+__device__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
   double neg_g[6], delta[6], rc;
-  for (int k = 0; k < 6; k++) neg_g[k] = -st.grad[k];
-  lu_solve6(st.hess, neg_g, delta, &rc);
-  if (!(rc > 1e-13)) svd_solve6_dev(st.hess, neg_g, delta);
+#pragma unroll
+  for (int k = 0; k < 6; k++) neg_g[k] = -s.grad[k];
+  gj_solve6_wave(s.hess, neg_g, delta, &rc);
+  if (!(rc > 1e-13)) svd_solve6_dev(s.hess, neg_g, delta);
   double norm = sqrt(dot6(delta, delta));
   if (norm == 0 || norm != norm) {
-    st.converged = (norm == norm) ? 1 : 0;
-    st.phase = PH_DONE;
+    s.converged = (norm == norm) ? 1 : 0;
+    s.phase = PH_DONE;
     return false;
   }
-  for (int k = 0; k < 6; k++) st.dir[k] = delta[k] / norm;
+#pragma unroll
+  for (int k = 0; k < 6; k++) s.dir[k] = delta[k] / norm;
   // computeStepLengthMT(p, dir, norm, step_size, eps / 2, ...)
-  st.phi_0 = -st.score;
-  st.d_phi_0 = -dot6(st.grad, st.dir);
-  st.step_init = norm;
-  if (st.d_phi_0 >= 0) {
-    if (st.d_phi_0 == 0) {
-      st.a_t = 0;  // "not a descent direction": zero step, no evaluation
+  s.phi_0 = -s.score;
+  s.d_phi_0 = -dot6(s.grad, s.dir);
+  s.step_init = norm;
+  if (s.d_phi_0 >= 0) {
+    if (s.d_phi_0 == 0) {
+      s.a_t = 0;  // "not a descent direction": zero step, no evaluation
       return false;
     }
-    st.d_phi_0 = -st.d_phi_0;
-    for (int k = 0; k < 6; k++) st.dir[k] = -st.dir[k];
+    s.d_phi_0 = -s.d_phi_0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s.dir[k] = -s.dir[k];
   }
   const double step_max = c.step_size, step_min = c.trans_eps / 2;
-  st.step_iterations = 0;
-  st.a_l = 0; st.a_u = 0;
-  st.f_l = mt_psi(0, st.phi_0, st.phi_0, st.d_phi_0, kMu);
-  st.g_l = mt_dpsi(st.d_phi_0, st.d_phi_0, kMu);
-  st.f_u = st.f_l;
-  st.g_u = st.g_l;
-  st.interval_converged = (c.line_search == DGS_NDT_LS_FIXED_STEP) ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
-  st.open_interval = 1;
-  double a_t = fmax(fmin(norm, step_max), step_min);
-  st.a_t = a_t;
+  s.step_iterations = 0;
+  s.a_l = 0; s.a_u = 0;
+  s.f_l = mt_psi(0, s.phi_0, s.phi_0, s.d_phi_0, kMu);
+  s.g_l = mt_dpsi(s.d_phi_0, s.d_phi_0, kMu);
+  s.f_u = s.f_l;
+  s.g_u = s.g_l;
+  s.interval_converged = (c.line_search == DGS_NDT_LS_FIXED_STEP) ? ((step_max - step_min) > 0) : ((step_max - step_min) < 0);
+  s.open_interval = 1;
+  const double a_t = fmax(fmin(norm, step_max), step_min);
+  s.a_t = a_t;
   double x[6];
-  for (int k = 0; k < 6; k++) x[k] = st.p[k] + st.dir[k] * a_t;
-  write_evaluation(st, c, x, 1, true);
-  st.phase = PH_MT_FIRST;
+#pragma unroll
+  for (int k = 0; k < 6; k++) x[k] = s.p[k] + s.dir[k] * a_t;
+  write_evaluation(st, s, c, x, 1, true, writer);
+  s.phase = PH_MT_FIRST;
   return true;
 }
 
 // p += a_t * dir; convergence test of computeTransformation.  Returns true when the registration ended.
-__device__ bool end_iteration(NdtPair& st, const NdtConsts& c) {
-  const double a = st.a_t;
-  for (int k = 0; k < 6; k++) st.p[k] += st.dir[k] * a;
-  if (st.traj_len < kTrajCap) {
-    for (int k = 0; k < 6; k++) st.traj[st.traj_len][k] = st.p[k];
+__device__ bool end_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
+  const double a = s.a_t;
+#pragma unroll
+  for (int k = 0; k < 6; k++) s.p[k] += s.dir[k] * a;
+  if (writer && s.traj_len < kTrajCap) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) st->traj[s.traj_len][k] = s.p[k];
   }
-  st.traj_len++;
+  s.traj_len++;
   bool conv = false;
-  if (st.nr_iterations > c.max_iterations || (st.nr_iterations && (fabs(a) < c.trans_eps))) conv = true;
-  st.nr_iterations++;
+  if (s.nr_iterations > c.max_iterations || (s.nr_iterations && (fabs(a) < c.trans_eps))) conv = true;
+  s.nr_iterations++;
   if (conv) {
-    st.converged = 1;
-    st.phase = PH_DONE;
+    s.converged = 1;
+    s.phase = PH_DONE;
   }
   return conv;
 }
 
-__device__ inline bool mt_keep_going(const NdtPair& st, const NdtConsts& c, double psi_t, double d_phi_t) {
-  return !st.interval_converged && st.step_iterations < c.mt_max_step_iterations && !(psi_t <= 0 && d_phi_t <= -kNu * st.d_phi_0);
+__device__ inline bool mt_keep_going(const NdtSolver& s, const NdtConsts& c, double psi_t, double d_phi_t) {
+  return !s.interval_converged && s.step_iterations < c.mt_max_step_iterations && !(psi_t <= 0 && d_phi_t <= -kNu * s.d_phi_0);
 }
 
-__device__ void queue_trial(NdtPair& st, const NdtConsts& c, double a_t) {
+__device__ void queue_trial(NdtPair* st, NdtSolver& s, const NdtConsts& c, double a_t, bool writer) {
   const double step_max = c.step_size, step_min = c.trans_eps / 2;
   a_t = fmax(fmin(a_t, step_max), step_min);
-  st.a_t = a_t;
+  s.a_t = a_t;
   double x[6];
-  for (int k = 0; k < 6; k++) x[k] = st.p[k] + st.dir[k] * a_t;
-  write_evaluation(st, c, x, 0, true);
-  st.phase = PH_MT_TRIAL;
+#pragma unroll
+  for (int k = 0; k < 6; k++) x[k] = s.p[k] + s.dir[k] * a_t;
+  write_evaluation(st, s, c, x, 0, true, writer);
+  s.phase = PH_MT_TRIAL;
 }
 
-// Consumes one evaluation result (already stored in st.score/grad/hess) and advances the state machine until
-// the next evaluation is queued or the registration is finished.
-__device__ void ndt_advance(NdtPair& st, const NdtConsts& c) {
-  st.evaluations++;
+// Consumes one evaluation result (already stored in s.score/grad/hess) and advances the state machine until
+// the next evaluation is queued or the registration is finished.  Executed by all lanes of one wave in lock step.
+__device__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
+  s.evaluations++;
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
-  switch (st.phase) {
+  switch (s.phase) {
     case PH_PROBE:
-      st.phase = PH_DONE;
+      s.phase = PH_DONE;
       return;
     case PH_INIT_EVAL:
       break;
     case PH_MT_FIRST:
     case PH_MT_TRIAL: {
-      const double phi_t = -st.score;
-      const double d_phi_t = -dot6(st.grad, st.dir);
-      const double psi_t = mt_psi(st.a_t, phi_t, st.phi_0, st.d_phi_0, kMu);
-      const double d_psi_t = mt_dpsi(d_phi_t, st.d_phi_0, kMu);
-      if (st.phase == PH_MT_TRIAL) {
-        if (st.open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
-          st.open_interval = 0;
-          st.f_l = st.f_l + st.phi_0 - kMu * st.d_phi_0 * st.a_l;
-          st.g_l = st.g_l + kMu * st.d_phi_0;
-          st.f_u = st.f_u + st.phi_0 - kMu * st.d_phi_0 * st.a_u;
-          st.g_u = st.g_u + kMu * st.d_phi_0;
+      const double phi_t = -s.score;
+      const double d_phi_t = -dot6(s.grad, s.dir);
+      const double psi_t = mt_psi(s.a_t, phi_t, s.phi_0, s.d_phi_0, kMu);
+      const double d_psi_t = mt_dpsi(d_phi_t, s.d_phi_0, kMu);
+      if (s.phase == PH_MT_TRIAL) {
+        if (s.open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+          s.open_interval = 0;
+          s.f_l = s.f_l + s.phi_0 - kMu * s.d_phi_0 * s.a_l;
+          s.g_l = s.g_l + kMu * s.d_phi_0;
+          s.f_u = s.f_u + s.phi_0 - kMu * s.d_phi_0 * s.a_u;
+          s.g_u = s.g_u + kMu * s.d_phi_0;
         }
-        if (st.open_interval)
-          st.interval_converged = mt_update_interval(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, psi_t, d_psi_t);
+        if (s.open_interval)
+          s.interval_converged = mt_update_interval(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, psi_t, d_psi_t);
         else
-          st.interval_converged = mt_update_interval(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, phi_t, d_phi_t);
-        st.step_iterations++;
+          s.interval_converged = mt_update_interval(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, phi_t, d_phi_t);
+        s.step_iterations++;
       }
-      if (mt_keep_going(st, c, psi_t, d_phi_t)) {
-        const double a_n = st.open_interval ? mt_trial_value(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, psi_t, d_psi_t)
-                                            : mt_trial_value(st.a_l, st.f_l, st.g_l, st.a_u, st.f_u, st.g_u, st.a_t, phi_t, d_phi_t);
-        queue_trial(st, c, a_n);
+      if (mt_keep_going(s, c, psi_t, d_phi_t)) {
+        const double a_n = s.open_interval ? mt_trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, psi_t, d_psi_t)
+                                           : mt_trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, phi_t, d_phi_t);
+        queue_trial(st, s, c, a_n, writer);
         return;
       }
-      if (st.step_iterations) {  // computeHessian at the accepted point
-        write_evaluation(st, c, st.x_t, 1, false);
-        st.phase = PH_MT_HESSIAN;
+      if (s.step_iterations) {  // computeHessian at the accepted point
+        double x[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) x[k] = s.x_t[k];
+        write_evaluation(st, s, c, x, 1, false, writer);
+        s.phase = PH_MT_HESSIAN;
         return;
       }
       iteration_open = true;
@@ -516,21 +526,21 @@ __device__ void ndt_advance(NdtPair& st, const NdtConsts& c) {
   }
   for (int guard = 0; guard < 4096; guard++) {
     if (iteration_open) {
-      if (end_iteration(st, c)) return;
+      if (end_iteration(st, s, c, writer)) return;
     }
-    if (begin_iteration(st, c)) return;  // evaluation queued
-    if (st.phase == PH_DONE) return;
-    iteration_open = true;               // zero-step iteration: close it and try again
+    if (begin_iteration(st, s, c, writer)) return;  // evaluation queued
+    if (s.phase == PH_DONE) return;
+    iteration_open = true;                          // zero-step iteration: close it and try again
   }
-  st.converged = 0;
-  st.phase = PH_DONE;
+  s.converged = 0;
+  s.phase = PH_DONE;
 }
 
 __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int blocks_per_pair,
                                                            const NdtConsts c, int* __restrict__ done_counter) {
   const int pair = blockIdx.x;
-  NdtPair& st = pairs[pair];
-  if (!st.active) return;
+  NdtPair* st = pairs + pair;
+  if (!st->active) return;
   // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
   __shared__ double sm[kBlock / kAccumPad][kAccumPad];
   const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
@@ -543,26 +553,37 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
   __shared__ double tot[kAccumPad];
   if (threadIdx.x < kAccumPad) {
     double t = 0.0;
+#pragma unroll
     for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
     tot[threadIdx.x] = t;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  st.score = tot[0];
-  for (int k = 0; k < 6; k++) st.grad[k] = tot[1 + k];
-  if (st.need_hessian) {
+  if (threadIdx.x >= kWave) return;
+  // ---- one wave advances the optimiser: state in registers, every lane computes the same values, lane 0 writes
+  const bool writer = threadIdx.x == 0;
+  NdtSolver s = st->s;
+  const int need_h = st->need_hessian;
+  s.score = tot[0];
+#pragma unroll
+  for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];
+  if (need_h) {
     int q = 7;
+#pragma unroll
     for (int i = 0; i < 6; i++)
+#pragma unroll
       for (int j = i; j < 6; j++) {
-        st.hess[i * 6 + j] = tot[q];
-        st.hess[j * 6 + i] = tot[q];
+        s.hess[i * 6 + j] = tot[q];
+        s.hess[j * 6 + i] = tot[q];
         q++;
       }
   }
-  ndt_advance(st, c);
-  if (st.phase == PH_DONE) {
-    st.active = 0;
-    atomicAdd(done_counter, 1);
+  ndt_advance(st, s, c, writer);
+  if (writer) {
+    st->s = s;
+    if (s.phase == PH_DONE) {
+      st->active = 0;
+      atomicAdd(done_counter, 1);
+    }
   }
 }
 
@@ -570,30 +591,32 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
 __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __restrict__ inits, int n_pairs, const NdtConsts c, int probe) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
-  NdtPair& st = pairs[i];
+  NdtPair* st = pairs + i;
   const NdtInit& in = inits[i];
-  for (int k = 0; k < 6; k++) st.p[k] = in.p0[k];
-  write_evaluation(st, c, in.p0, 1, false);
+  NdtSolver s;
+  s.phase = probe ? PH_PROBE : PH_INIT_EVAL;
+  s.nr_iterations = 0;
+  s.evaluations = 0;
+  s.converged = 0;
+  s.step_iterations = 0;
+  s.interval_converged = 0;
+  s.open_interval = 1;
+  s.traj_len = 1;
+  s.score = 0;
+  s.phi_0 = s.d_phi_0 = s.a_t = s.a_l = s.f_l = s.g_l = s.a_u = s.f_u = s.g_u = s.step_init = 0;
+  for (int k = 0; k < 6; k++) { s.p[k] = in.p0[k]; s.grad[k] = 0; s.dir[k] = 0; st->traj[0][k] = in.p0[k]; }
+  for (int k = 0; k < 36; k++) s.hess[k] = 0;
+  double x[6];
+  for (int k = 0; k < 6; k++) x[k] = in.p0[k];
+  write_evaluation(st, s, c, x, 1, false, true);
   // the first evaluation transforms the cloud by the GUESS matrix itself (computeTransformation)
   const float* G = in.guess;
-  st.T[0] = G[0]; st.T[1] = G[4]; st.T[2] = G[8];  st.T[3] = G[12];
-  st.T[4] = G[1]; st.T[5] = G[5]; st.T[6] = G[9];  st.T[7] = G[13];
-  st.T[8] = G[2]; st.T[9] = G[6]; st.T[10] = G[10]; st.T[11] = G[14];
-  for (int k = 0; k < 16; k++) st.final_T[k] = G[k];
-  st.phase = probe ? PH_PROBE : PH_INIT_EVAL;
-  for (int k = 0; k < 6; k++) st.traj[0][k] = in.p0[k];
-  st.traj_len = 1;
-  st.active = 1;
-  st.nr_iterations = 0;
-  st.evaluations = 0;
-  st.converged = 0;
-  st.step_iterations = 0;
-  st.interval_converged = 0;
-  st.open_interval = 1;
-  st.score = 0;
-  st.a_t = 0;
-  for (int k = 0; k < 6; k++) { st.grad[k] = 0; st.dir[k] = 0; }
-  for (int k = 0; k < 36; k++) st.hess[k] = 0;
+  st->T[0] = G[0]; st->T[1] = G[4]; st->T[2] = G[8];  st->T[3] = G[12];
+  st->T[4] = G[1]; st->T[5] = G[5]; st->T[6] = G[9];  st->T[7] = G[13];
+  st->T[8] = G[2]; st->T[9] = G[6]; st->T[10] = G[10]; st->T[11] = G[14];
+  for (int k = 0; k < 16; k++) st->final_T[k] = G[k];
+  st->s = s;
+  st->active = 1;
 }
 
 struct NdtOut {
@@ -608,11 +631,11 @@ __global__ void ndt_export_kernel(const NdtPair* __restrict__ pairs, int n_pairs
   const NdtPair& st = pairs[i];
   NdtOut o;
   for (int k = 0; k < 16; k++) o.T[k] = st.final_T[k];
-  o.converged = (st.phase == PH_DONE) ? st.converged : 0;
-  o.iterations = st.nr_iterations;
-  o.evaluations = st.evaluations;
+  o.converged = (st.s.phase == PH_DONE) ? st.s.converged : 0;
+  o.iterations = st.s.nr_iterations;
+  o.evaluations = st.s.evaluations;
   o.pad = 0;
-  o.score = st.score;
+  o.score = st.s.score;
   out[i] = o;
 }
 
@@ -812,7 +835,7 @@ int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len) {
   DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
   DGS_HIP_TRY(h, hipMemcpy(buf.data(), h->pairs.ptr + pair, sizeof(NdtPair), hipMemcpyDeviceToHost));
   const NdtPair* st = reinterpret_cast<const NdtPair*>(buf.data());
-  const int n = std::min(st->traj_len, kTrajCap);
+  const int n = std::min(st->s.traj_len, kTrajCap);
   for (int i = 0; i < n; i++)
     for (int k = 0; k < 6; k++) out[i * 6 + k] = st->traj[i][k];
   *len = n;
@@ -851,9 +874,9 @@ int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, 
   DGS_HIP_TRY(h, hipMemcpyAsync(hp, h->pairs.ptr, sizeof(NdtPair), hipMemcpyDeviceToHost, st));
   DGS_HIP_TRY(h, hipStreamSynchronize(st));
   DGS_HIP_TRY(h, hipGetLastError());
-  *score = hp->score;
-  for (int k = 0; k < 6; k++) g6[k] = hp->grad[k];
-  for (int k = 0; k < 36; k++) H36[k] = hp->hess[k];
+  *score = hp->s.score;
+  for (int k = 0; k < 6; k++) g6[k] = hp->s.grad[k];
+  for (int k = 0; k < 36; k++) H36[k] = hp->s.hess[k];
   return DGS_OK;
 }
 

@@ -7,13 +7,18 @@
 //   registration->getSearchMethodTarget()->nearestKSearch(pt,1,..) apps/scan_matching_odometry_nodelet.cpp:327
 // (in-tree statement of the same loop: src/hdl_graph_slam/information_matrix_calculator.cpp:77-108).
 //
-// MI355X design: no pointer-chasing kd-tree.  Points are sorted by 30-bit Morton code (one radix sort); an
-// IMPLICIT complete binary tree of AABBs over 8-point leaves sits on top (heap order, no child pointers, built
-// bottom-up by min/max of two children).  A query first takes an upper bound from the leaf at its own Morton
-// position, then walks the tree stacklessly (heap-index arithmetic) pruning on exact float AABB distances, so
-// the search is exact and unbounded (fitness_score_max_range defaults to DBL_MAX, loop_detector.hpp:46).
-// Squared distances are formed with explicitly rounded mul/add in FLANN's L2_Simple order (dx^2 + dy^2 + dz^2),
-// so they are bit-identical to a CPU float evaluation; ties resolve to the lowest original index.
+// MI355X design.  A per-lane kd-tree walk is bound by the texture-addresser: every lane of a wave touches its own
+// cache line at every step (measured: 215 dependent steps x 3 uncoalesced 16-B loads per query, 0.68 ms per 64k
+// queries).  So the index is an 8-ARY implicit tree over Morton-sorted points and EIGHT LANES share one query:
+//   * points are sorted by 30-bit Morton code (one radix sort); a leaf is 8 consecutive points = one 128-B line;
+//   * an internal node stores its 8 children's AABBs contiguously (two 128-B lines), heap order, no pointers;
+//   * at a node each lane of the group tests one child box (the group reads exactly two full lines), the group
+//     ballots the children whose box is within the current best, descends nearest-first and keeps one pending-children
+//     byte per level (5 levels for 64k points) -- no stack, no scratch; at the last level the boxes stay in registers
+//     while the qualifying leaves are scanned, each leaf scan being one coalesced line with one point per lane.
+// The search is exact and unbounded (fitness_score_max_range defaults to DBL_MAX, loop_detector.hpp:46).  Squared
+// distances are formed with individually rounded mul/add in FLANN's L2_Simple order (dx^2 + dy^2 + dz^2), so they
+// equal a CPU float evaluation bit for bit; pruning uses <= and ties resolve to the lowest original index.
 #include <hipcub/hipcub.hpp>
 
 #include <cfloat>
@@ -23,17 +28,16 @@
 
 namespace dgs {
 
-constexpr int kLeaf = 8;
+constexpr int kLeaf = 8;    // points per leaf = lanes per query group
+constexpr int kFan = 8;     // children per node
 
 struct BvhView {
-  const float4* sorted;   // Morton order, w = original index (bit pattern)
-  const float4* lo;
-  const float4* hi;
-  const uint32_t* keys;   // sorted Morton codes
+  const float4* sorted;   // Morton order, padded to a multiple of 8; w = original index (bit pattern), -1 for padding
+  const float4* box_lo;   // [node * 8 + child]
+  const float4* box_hi;
   int n;
-  int leaves;             // power of two
-  float org[3];
-  float scale;            // Morton quantisation: q = (x - org) * scale, clamped to [0, 1023]
+  int depth;              // internal levels D; leaf slots = 8^D
+  int first_leaf;         // heap index of leaf slot 0 = (8^D - 1) / 7
 };
 
 __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
@@ -75,103 +79,151 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict
   vals[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(kBlock) void gather_index_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ order, int n,
+__global__ __launch_bounds__(kBlock) void gather_index_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ order, int n, int n_pad,
                                                               float4* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t o = order[i];
-  float4 p = pts[o];
-  p.w = __uint_as_float(o);
-  out[i] = p;
-}
-
-__global__ __launch_bounds__(kBlock) void bvh_leaf_kernel(const float4* __restrict__ sorted, int n, int leaves, float4* __restrict__ lo,
-                                                          float4* __restrict__ hi) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= leaves) return;
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int k = 0; k < kLeaf; k++) {
-    const int i = j * kLeaf + k;
-    if (i < n) {
-      const float4 p = sorted[i];
-      if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-      }
-    }
+  if (i >= n_pad) return;
+  if (i < n) {
+    const uint32_t o = order[i];
+    float4 p = pts[o];
+    p.w = __uint_as_float(o);
+    out[i] = p;
+  } else {
+    out[i] = make_float4(NAN, NAN, NAN, __uint_as_float(0xFFFFFFFFu));  // padding: distance is NaN, never selected
   }
-  const int node = leaves - 1 + j;
-  lo[node] = make_float4(mn[0], mn[1], mn[2], 0.f);
-  hi[node] = make_float4(mx[0], mx[1], mx[2], 0.f);
 }
 
-__global__ __launch_bounds__(kBlock) void bvh_level_kernel(int first, int count, float4* __restrict__ lo, float4* __restrict__ hi) {
+// boxes of the nodes at one level (first .. first+count-1), written into their parents' child-box arrays
+__global__ __launch_bounds__(kBlock) void bvh_boxes_kernel(const float4* __restrict__ sorted, int n, int first, int count, int is_leaf_level,
+                                                           int first_leaf, float4* __restrict__ box_lo, float4* __restrict__ box_hi) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
   const int node = first + t;
-  const float4 l0 = lo[2 * node + 1], l1 = lo[2 * node + 2], h0 = hi[2 * node + 1], h1 = hi[2 * node + 2];
-  lo[node] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.f);
-  hi[node] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.f);
-}
-
-// ---- query ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void scan_leaf(const BvhView& b, int leaf, float x, float y, float z, float& best, int& best_idx) {
-  const int base = leaf * kLeaf;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (is_leaf_level) {
+    const int j = node - first_leaf;
 #pragma unroll
-  for (int k = 0; k < kLeaf; k++) {
-    const int i = base + k;
-    if (i < b.n) {
-      const float4 p = b.sorted[i];
-      const float d = sqdist_rn(x, y, z, p.x, p.y, p.z);
-      const int oi = (int)__float_as_uint(p.w);
-      if (d < best || (d == best && oi < best_idx)) {
-        best = d;
-        best_idx = oi;
+    for (int k = 0; k < kLeaf; k++) {
+      const int i = j * kLeaf + k;
+      if (i < n) {
+        const float4 p = sorted[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+          mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+          mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        }
       }
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kFan; k++) {
+      const float4 l = box_lo[node * kFan + k], h = box_hi[node * kFan + k];
+      mn[0] = fminf(mn[0], l.x); mn[1] = fminf(mn[1], l.y); mn[2] = fminf(mn[2], l.z);
+      mx[0] = fmaxf(mx[0], h.x); mx[1] = fmaxf(mx[1], h.y); mx[2] = fmaxf(mx[2], h.z);
+    }
   }
+  const int parent = (node - 1) / kFan, slot = (node - 1) % kFan;
+  box_lo[parent * kFan + slot] = make_float4(mn[0], mn[1], mn[2], 0.f);
+  box_hi[parent * kFan + slot] = make_float4(mx[0], mx[1], mx[2], 0.f);
 }
 
-__device__ void nn_query(const BvhView& b, float x, float y, float z, float& best, int& best_idx) {
+// ---- cross-lane helpers inside an 8-lane group (DPP: no LDS traffic) -------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned group8_min_u32(unsigned v) {
+  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror: lane i <-> 7 - i within each 8 lanes
+  return v;
+}
+__device__ __forceinline__ float group8_min_f32(float v) {
+  v = fminf(v, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v))));
+  v = fminf(v, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v))));
+  v = fminf(v, __uint_as_float(dpp_u32<0x141>(__float_as_uint(v))));
+  return v;
+}
+
+// Exact 1-NN of (x, y, z) for the 8-lane group this lane belongs to; x, y, z must be equal across the group.
+// All 8 lanes return the same (best, best_idx).  Lanes of a wave whose group is idle must still call this with
+// `alive` = false (they follow the control flow and touch no memory beyond node 0).
+__device__ void nn_query_group(const BvhView& b, float x, float y, float z, bool alive, float& best, int& best_idx) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7, gshift = lane & ~7;
   best = INFINITY;
   best_idx = 0x7FFFFFFF;
-  // upper bound from the leaf at the query's own Morton position
-  const uint32_t code = morton30(x, y, z, b.org, b.scale);
-  int lo = 0, hi = b.n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (b.keys[mid] < code) lo = mid + 1; else hi = mid;
-  }
-  const int leaf0 = min(lo, b.n - 1) / kLeaf;
-  scan_leaf(b, leaf0, x, y, z, best, best_idx);
-  const int first_leaf = b.leaves - 1;
-  int node = 0;
-  for (;;) {
-    const float d = aabb_sqdist_rn(b.lo[node], b.hi[node], x, y, z);
-    if (d <= best) {
-      if (node >= first_leaf) {
-        if (node - first_leaf != leaf0) scan_leaf(b, node - first_leaf, x, y, z, best, best_idx);
+  int node = 0, level = 0;
+  unsigned long long pend = 0ull;  // one byte of not-yet-visited qualifying children per level
+  bool fresh = true;
+  bool done = !alive;
+  while (__any(!done)) {
+    if (!done) {
+      const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
+      const float d = aabb_sqdist_rn(lo, hi, x, y, z);
+      // empty slots carry inverted boxes (distance +inf): never enter them, even while best is still +inf
+      unsigned mask = (unsigned)((__ballot(d <= best && d < INFINITY) >> gshift) & 0xFFull);
+      if (!fresh) mask &= (unsigned)((pend >> (8 * level)) & 0xFFull);
+      const bool last = (level + 1 == b.depth);
+      if (last) {
+        // children are leaves: scan every qualifying one nearest-first; the boxes stay in registers
+        while (mask) {
+          const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+          const int c = (int)(group8_min_u32(key) & 7u);
+          mask &= ~(1u << c);
+          const int leaf = (node * kFan + 1 + c) - b.first_leaf;
+          const float4 p = b.sorted[leaf * kLeaf + sub];
+          float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
+          if (!(dp == dp)) dp = INFINITY;  // padding / non-finite points
+          const float dmin = group8_min_f32(dp);
+          const unsigned oi = (dp == dmin) ? __float_as_uint(p.w) : 0xFFFFFFFFu;
+          const unsigned imin = group8_min_u32(oi);
+          if (dmin < best || (dmin == best && (int)imin < best_idx)) {
+            best = dmin;
+            best_idx = (int)imin;
+          }
+          mask &= (unsigned)((__ballot(d <= best) >> gshift) & 0xFFull);
+        }
+        // pop
+        fresh = false;
+        if (level == 0) {
+          done = true;
+        } else {
+          level--;
+          node = (node - 1) / kFan;
+        }
+      } else if (mask) {
+        const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+        const int c = (int)(group8_min_u32(key) & 7u);
+        mask &= ~(1u << c);
+        pend = (pend & ~(0xFFull << (8 * level))) | ((unsigned long long)mask << (8 * level));
+        node = node * kFan + 1 + c;
+        level++;
+        fresh = true;
       } else {
-        node = 2 * node + 1;
-        continue;
+        fresh = false;
+        if (level == 0) {
+          done = true;
+        } else {
+          level--;
+          node = (node - 1) / kFan;
+        }
       }
     }
-    while (node != 0 && (node & 1) == 0) node = (node - 1) >> 1;  // climb while we are a right child
-    if (node == 0) break;
-    node += 1;  // right sibling
   }
 }
 
 __global__ __launch_bounds__(kBlock) void nn_search_kernel(const BvhView b, const float4* __restrict__ q, int m, int* __restrict__ idx,
                                                            float* __restrict__ sq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  const float4 p = q[i];
+  const int qi = (blockIdx.x * kBlock + threadIdx.x) >> 3;  // one query per 8 lanes
+  const bool alive = qi < m;
+  const float4 p = alive ? q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
   float best;
   int bi;
-  nn_query(b, p.x, p.y, p.z, best, bi);
-  idx[i] = bi;
-  sq[i] = best;
+  nn_query_group(b, p.x, p.y, p.z, alive, best, bi);
+  if (alive && (threadIdx.x & 7) == 0) {
+    idx[qi] = bi;
+    sq[qi] = best;
+  }
 }
 
 // fitness / inlier accumulation: per block one row {sum d2 (d2 <= max_range), count, inliers (d2 < inlier_sq)}
@@ -185,20 +237,27 @@ __global__ __launch_bounds__(kBlock) void nn_fitness_kernel(const BvhView b, con
   const float t00 = T[0], t10 = T[1], t20 = T[2], t01 = T[4], t11 = T[5], t21 = T[6], t02 = T[8], t12 = T[9], t22 = T[10], t03 = T[12],
               t13 = T[13], t23 = T[14];
   double s = 0.0, c = 0.0, inl = 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
-    const float4 p = src[i];
-    // pcl::transformPointCloud: ((m0 x + m1 y) + m2 z) + m3 in float
-    const float x = add_rn(add_rn(add_rn(mul_rn(t00, p.x), mul_rn(t01, p.y)), mul_rn(t02, p.z)), t03);
-    const float y = add_rn(add_rn(add_rn(mul_rn(t10, p.x), mul_rn(t11, p.y)), mul_rn(t12, p.z)), t13);
-    const float z = add_rn(add_rn(add_rn(mul_rn(t20, p.x), mul_rn(t21, p.y)), mul_rn(t22, p.z)), t23);
+  constexpr int QPB = kBlock / 8;  // queries per block per sweep
+  const int sub = threadIdx.x & 7;
+  const int sweeps = (n + blocks_per_pair * QPB - 1) / (blocks_per_pair * QPB);
+  for (int sw = 0; sw < sweeps; sw++) {
+    const int i = (sw * blocks_per_pair + blockIdx.x) * QPB + (threadIdx.x >> 3);
+    const bool alive = i < n;
+    const float4 p = alive ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // pcl::transformPointCloud: ((m0 x + m1 y) + m2 z) + m3 in float, every step rounded
+    const float x = affine_row_rn(t00, t01, t02, t03, p.x, p.y, p.z);
+    const float y = affine_row_rn(t10, t11, t12, t13, p.x, p.y, p.z);
+    const float z = affine_row_rn(t20, t21, t22, t23, p.x, p.y, p.z);
     float best;
     int bi;
-    nn_query(b, x, y, z, best, bi);
-    if (best <= max_range) {  // PCL compares the SQUARED distance with max_range
-      s += (double)best;
-      c += 1.0;
+    nn_query_group(b, x, y, z, alive, best, bi);
+    if (alive && sub == 0) {
+      if (best <= max_range) {  // PCL compares the SQUARED distance with max_range
+        s += (double)best;
+        c += 1.0;
+      }
+      if (best < inlier_sq) inl += 1.0;
     }
-    if (best < inlier_sq) inl += 1.0;
   }
   __shared__ double sm[kBlock / kWave][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -237,19 +296,21 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
   if (rc) return rc;
   if (!(mm[0] <= mm[3])) { mm[0] = mm[1] = mm[2] = 0.f; mm[3] = mm[4] = mm[5] = 1.f; }
   const float ext = std::max(std::max(mm[3] - mm[0], mm[4] - mm[1]), std::max(mm[5] - mm[2], 1e-6f));
-  int leaves = 1;
-  while ((int64_t)leaves * kLeaf < n) leaves <<= 1;
-  int levels = 1;
-  while ((1 << (levels - 1)) < leaves) levels++;
-  bvh.leaves = leaves;
-  bvh.levels = levels;
-  DGS_HIP_TRY(h, bvh.sorted.reserve(n));
+  const int n_leaves = (n + kLeaf - 1) / kLeaf;
+  int depth = 1;
+  int64_t slots = kFan;
+  while (slots < n_leaves) { slots *= kFan; depth++; }
+  const int first_leaf = (int)((slots - 1) / (kFan - 1));
+  const int n_pad = n_leaves * kLeaf;
+  bvh.leaves = (int)slots;
+  bvh.levels = depth;
+  DGS_HIP_TRY(h, bvh.sorted.reserve(n_pad));
   DGS_HIP_TRY(h, bvh.keys.reserve(n));
   DGS_HIP_TRY(h, bvh.keys_alt.reserve(n));
   DGS_HIP_TRY(h, bvh.vals.reserve(n));
   DGS_HIP_TRY(h, bvh.vals_alt.reserve(n));
-  DGS_HIP_TRY(h, bvh.node_lo.reserve((size_t)2 * leaves));
-  DGS_HIP_TRY(h, bvh.node_hi.reserve((size_t)2 * leaves));
+  DGS_HIP_TRY(h, bvh.node_lo.reserve((size_t)first_leaf * kFan));
+  DGS_HIP_TRY(h, bvh.node_hi.reserve((size_t)first_leaf * kFan));
   size_t tb = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st);
   DGS_HIP_TRY(h, h->cub_temp.reserve(tb + 256));
@@ -258,11 +319,16 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
   hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, mm[0], mm[1], mm[2], scale, bvh.keys.ptr, bvh.vals.ptr);
   tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st));
-  hipLaunchKernelGGL(gather_index_kernel, dim3(nb), dim3(kBlock), 0, st, pts, bvh.vals_alt.ptr, n, bvh.sorted.ptr);
-  hipLaunchKernelGGL(bvh_leaf_kernel, dim3((leaves + kBlock - 1) / kBlock), dim3(kBlock), 0, st, bvh.sorted.ptr, n, leaves, bvh.node_lo.ptr, bvh.node_hi.ptr);
-  for (int l = levels - 2; l >= 0; l--) {
-    const int count = 1 << l, first = count - 1;
-    hipLaunchKernelGGL(bvh_level_kernel, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, st, first, count, bvh.node_lo.ptr, bvh.node_hi.ptr);
+  hipLaunchKernelGGL(gather_index_kernel, dim3((n_pad + kBlock - 1) / kBlock), dim3(kBlock), 0, st, pts, bvh.vals_alt.ptr, n, n_pad, bvh.sorted.ptr);
+  // leaf slots first, then every internal level bottom-up (the root's own box is never needed)
+  hipLaunchKernelGGL(bvh_boxes_kernel, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, bvh.sorted.ptr, n, first_leaf, (int)slots, 1,
+                     first_leaf, bvh.node_lo.ptr, bvh.node_hi.ptr);
+  int64_t count = slots / kFan;
+  for (int l = depth - 1; l >= 1; l--) {
+    const int first = (int)((count - 1) / (kFan - 1));
+    hipLaunchKernelGGL(bvh_boxes_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, bvh.sorted.ptr, n, first, (int)count, 0,
+                       first_leaf, bvh.node_lo.ptr, bvh.node_hi.ptr);
+    count /= kFan;
   }
   DGS_HIP_TRY(h, hipGetLastError());
   bvh.org[0] = mm[0]; bvh.org[1] = mm[1]; bvh.org[2] = mm[2];
@@ -274,13 +340,11 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
 static BvhView make_view(const Bvh& b) {
   BvhView v;
   v.sorted = b.sorted.ptr;
-  v.lo = b.node_lo.ptr;
-  v.hi = b.node_hi.ptr;
-  v.keys = b.keys_alt.ptr;
+  v.box_lo = b.node_lo.ptr;
+  v.box_hi = b.node_hi.ptr;
   v.n = (int)b.n;
-  v.leaves = b.leaves;
-  v.org[0] = b.org[0]; v.org[1] = b.org[1]; v.org[2] = b.org[2];
-  v.scale = b.scale;
+  v.depth = b.levels;
+  v.first_leaf = (int)(((int64_t)b.leaves - 1) / (kFan - 1));
   return v;
 }
 
@@ -294,7 +358,7 @@ int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, f
   if (rc) return rc;
   const BvhView v = make_view(h->target_bvh);
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
-  hipLaunchKernelGGL(nn_search_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, queries, (int)m, d_idx, d_sq);
+  hipLaunchKernelGGL(nn_search_kernel, dim3((unsigned)((m * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, queries, (int)m, d_idx, d_sq);
   prof_end(h, DGS_K_NN_SEARCH, slot);
   DGS_HIP_TRY(h, hipGetLastError());
   return DGS_OK;
@@ -306,8 +370,8 @@ int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs
   if (rc) return rc;
   hipStream_t st = h->stream;
   const BvhView v = make_view(h->target_bvh);
-  const int full = std::max(1, (max_size + kBlock - 1) / kBlock);
-  const int bpp = std::max(1, std::min(full, std::max(8, 2048 / std::max(1, n_pairs))));
+  const int full = std::max(1, (int)(((int64_t)max_size * 8 + kBlock - 1) / kBlock));  // one query per 8 lanes
+  const int bpp = std::max(1, std::min(full, std::max(64, 8192 / std::max(1, n_pairs))));
   DGS_HIP_TRY(h, h->nn_partials.reserve((size_t)n_pairs * bpp * 4 + (size_t)n_pairs * 4));
   double* d_out = h->nn_partials.ptr + (size_t)n_pairs * bpp * 4;
   if (ensure_pinned(h, 4096 + sizeof(double) * 4 * n_pairs) != DGS_OK) return DGS_ERR_HIP;
