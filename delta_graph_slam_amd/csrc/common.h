@@ -150,4 +150,22 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Wave64 sum through DPP (no LDS crossbar traffic): row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15 / 31
+// across rows.  The total lands in lane 63 only; the order of additions is fixed, so the result is reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return v;
+}
+
 }  // namespace dgs

@@ -64,7 +64,8 @@ __device__ __forceinline__ void neighbour_offset(int k, int& dx, int& dy, int& d
 template <int SEARCH>
 __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
                                                                  const NdtPair* __restrict__ pairs, const VoxelGrid g, const float gd1,
-                                                                 const float gd2, double* __restrict__ partials, const int blocks_per_pair) {
+                                                                 const float gd2, const int leaf_pow2, double* __restrict__ partials,
+                                                                 const int blocks_per_pair) {
   const int pair = blockIdx.y;
   const NdtPair& st = pairs[pair];
   if (!st.active) return;
@@ -88,18 +89,33 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
     const float xt0 = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
     const float xt1 = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
     const float xt2 = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
-    const int c0 = (int)floorf(xt0 / g.leaf), c1 = (int)floorf(xt1 / g.leaf), c2 = (int)floorf(xt2 / g.leaf);
+    // getNeighborhoodAtPoint: floor(x / leaf_size); x * (1 / leaf) is the same number when leaf is a power of two
+    const int c0 = (int)floorf(leaf_pow2 ? xt0 * g.inv_leaf : xt0 / g.leaf);
+    const int c1 = (int)floorf(leaf_pow2 ? xt1 * g.inv_leaf : xt1 / g.leaf);
+    const int c2 = (int)floorf(leaf_pow2 ? xt2 * g.inv_leaf : xt2 / g.leaf);
 
     // ---- gather: voxel ids of the neighbourhood (independent loads, issued together)
     constexpr int NB = Offsets<SEARCH>::N;
     int vid[NB];
+    // interior cells (every neighbour inside the grid) need no per-neighbour bounds test: base pointer + fixed offsets
+    const bool interior = c0 > g.min_b[0] && c0 < g.max_b[0] && c1 > g.min_b[1] && c1 < g.max_b[1] && c2 > g.min_b[2] && c2 < g.max_b[2];
+    if (interior) {
+      const int* __restrict__ base = g.cell2vox + ((c0 - g.min_b[0]) + (c1 - g.min_b[1]) * g.mul1 + (c2 - g.min_b[2]) * g.mul2);
 #pragma unroll
-    for (int k = 0; k < NB; k++) {
-      int dx, dy, dz;
-      neighbour_offset<SEARCH>(k, dx, dy, dz);
-      const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
-      const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
-      vid[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+      for (int k = 0; k < NB; k++) {
+        int dx, dy, dz;
+        neighbour_offset<SEARCH>(k, dx, dy, dz);
+        vid[k] = base[dx + dy * g.mul1 + dz * g.mul2];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        int dx, dy, dz;
+        neighbour_offset<SEARCH>(k, dx, dy, dz);
+        const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
+        const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
+        vid[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+      }
     }
 
     // ---- fold the neighbourhood:  A = sum w C,  b = sum w C q,  M = sum w d2 (Cq)(Cq)^T,  score
@@ -114,12 +130,13 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
         if (!(ex * ex + ey * ey + ez * ez < r2)) continue;
       }
       const VoxelRec* __restrict__ rec = g.vox + vid[k];
-      const double2 m01 = *reinterpret_cast<const double2*>(&rec->mean[0]);
-      const double m2 = rec->mean[2];
-      const float4 ca = *reinterpret_cast<const float4*>(&rec->icov[0]);
-      const float2 cb = *reinterpret_cast<const float2*>(&rec->icov[4]);
-      const float q0 = (float)((double)xt0 - m01.x), q1 = (float)((double)xt1 - m01.y), q2 = (float)((double)xt2 - m2);
-      const float Cxx = ca.x, Cxy = ca.y, Cxz = ca.z, Cyy = ca.w, Cyz = cb.x, Czz = cb.y;
+      const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);  // three aligned 16-B loads
+      const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+      const double mx = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x));
+      const double my = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z));
+      const double mz = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
+      const float q0 = (float)((double)xt0 - mx), q1 = (float)((double)xt1 - my), q2 = (float)((double)xt2 - mz);
+      const float Cxx = rb.z, Cxy = rb.w, Cxz = rc.x, Cyy = rc.y, Cyz = rc.z, Czz = rc.w;
       const float u0 = q0 * Cxx + q1 * Cxy + q2 * Cxz;
       const float u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
       const float u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
@@ -183,8 +200,8 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < kAccum; k++) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) sm[wave][k] = v;
+    const double v = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) sm[wave][k] = v;
   }
   __syncthreads();
   if (threadIdx.x < kAccumPad) {
@@ -680,23 +697,25 @@ static void fill_consts(dgs_handle* h) {
 static void launch_derivatives(dgs_handle* h, int n_pairs, int bpp) {
   const dim3 grid(bpp, n_pairs), block(kBlock);
   const float gd1 = (float)h->consts.gauss_d1, gd2 = (float)h->consts.gauss_d2;
+  int fe = 0;
+  const int leaf_pow2 = (std::frexp(h->grid.leaf, &fe) == 0.5f) ? 1 : 0;
   int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES);
   switch (h->consts.search_method) {
     case DGS_NDT_DIRECT1:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT1>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
       break;
     case DGS_NDT_DIRECT26:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT26>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
       break;
     case DGS_NDT_KDTREE:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_KDTREE>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
       break;
     default:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT7>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
       break;
   }
   prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
@@ -710,7 +729,7 @@ static void launch_solve(dgs_handle* h, int n_pairs, int bpp) {
 
 static int choose_blocks_per_pair(int n_pairs, int max_n) {
   const int full = std::max(1, (max_n + kBlock - 1) / kBlock);     // one point per lane
-  const int share = std::max(8, 2048 / std::max(1, n_pairs));      // keep the whole launch near 2048 workgroups
+  const int share = std::max(8, 1024 / std::max(1, n_pairs));      // keep the whole launch near 1024 workgroups (4 per CU)
   return std::max(1, std::min(std::min(full, share), kMaxPartialBlocks));
 }
 

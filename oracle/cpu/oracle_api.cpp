@@ -2,6 +2,7 @@
 #include "oracle_api.h"
 #include "linalg.hpp"
 #include "ndt_cpu.hpp"
+#include "gicp_cpu.hpp"
 #include <cstring>
 #ifdef _OPENMP
 #include <omp.h>
@@ -113,4 +114,70 @@ int32_t orc_max_threads(void) {
   return 1;
 #endif
 }
+
+void orc_gicp_default_params(orc_gicp_params* p) {
+  GicpParams d;
+  p->transformation_epsilon = d.transformation_epsilon;
+  p->rotation_epsilon = d.rotation_epsilon;
+  p->max_correspondence_distance = d.max_correspondence_distance;
+  p->lm_init_lambda_factor = d.lm_init_lambda_factor;
+  p->max_iterations = d.max_iterations;
+  p->k_correspondences = d.k_correspondences;
+  p->regularization = d.regularization;
+  p->optimizer = d.optimizer;
+  p->lm_max_iterations = d.lm_max_iterations;
+  p->num_threads = d.num_threads;
+}
+void* orc_gicp_create(const orc_gicp_params* p) {
+  GicpParams d;
+  d.transformation_epsilon = p->transformation_epsilon;
+  d.rotation_epsilon = p->rotation_epsilon;
+  d.max_correspondence_distance = p->max_correspondence_distance;
+  d.lm_init_lambda_factor = p->lm_init_lambda_factor;
+  d.max_iterations = p->max_iterations;
+  d.k_correspondences = p->k_correspondences;
+  d.regularization = p->regularization;
+  d.optimizer = p->optimizer;
+  d.lm_max_iterations = p->lm_max_iterations;
+  d.num_threads = p->num_threads;
+  return new GicpCpu(d);
+}
+void orc_gicp_destroy(void* h) { delete static_cast<GicpCpu*>(h); }
+void orc_gicp_set_target(void* h, const float* xyz16, int64_t n) { static_cast<GicpCpu*>(h)->set_target(xyz16, n); }
+void orc_gicp_set_source(void* h, const float* xyz16, int64_t n) { static_cast<GicpCpu*>(h)->set_source(xyz16, n); }
+void orc_gicp_align(void* h, const float* guess16, orc_result* out) {
+  GicpResult r = static_cast<GicpCpu*>(h)->align(guess16);
+  std::memcpy(out->T, r.T, sizeof(r.T));
+  out->converged = r.converged;
+  out->iterations = r.iterations;
+  out->evaluations = r.evaluations;
+  out->pad = 0;
+  out->score = r.error;
+}
+double orc_gicp_linearize(void* h, const double* T, double* H36, double* b6) { return static_cast<GicpCpu*>(h)->linearize(T, H36, b6); }
+double orc_gicp_compute_error(void* h, const double* T) { return static_cast<GicpCpu*>(h)->compute_error(T); }
+void orc_gicp_covariances(void* h, int32_t which, double* out9) {
+  GicpCpu* g = static_cast<GicpCpu*>(h);
+  g->ensure_covariances();
+  const std::vector<double>& c = which ? g->cov_t : g->cov_s;
+  std::memcpy(out9, c.data(), c.size() * sizeof(double));
+}
+void orc_gicp_correspondences(void* h, int32_t* corr, float* sq_dist) {
+  GicpCpu* g = static_cast<GicpCpu*>(h);
+  for (size_t i = 0; i < g->corr.size(); i++) { corr[i] = g->corr[i]; sq_dist[i] = g->sq_dist[i]; }
+}
+double orc_fitness_score(const float* target, int64_t nt, const float* source, int64_t ns, const float* T16, double max_range, double inlier_sq,
+                         int64_t* n_used, int64_t* n_inliers) {
+  return fitness_score(target, nt, source, ns, T16, max_range, inlier_sq, n_used, n_inliers);
+}
+void orc_knn(const float* cloud, int64_t n, const float* queries, int64_t m, int32_t k, int32_t* idx, float* d2) {
+  KdTree t;
+  t.build(cloud, n);
+#pragma omp parallel for schedule(guided, 8)
+  for (int64_t i = 0; i < m; i++) {
+    const int found = t.knn(queries + i * 4, k, idx + i * k, d2 + i * k);
+    for (int j = found; j < k; j++) { idx[i * k + j] = -1; d2[i * k + j] = INFINITY; }
+  }
+}
+void orc_se3_exp(const double* a6, double* T) { se3_exp(a6, T); }
 }

@@ -36,6 +36,27 @@ void orc_ldlt_solve6(const double* A36, const double* b6, double* x6);
 void orc_sym_eig3(const double* A9, double* evals3, double* V9);
 int32_t orc_max_threads(void);
 
+typedef struct orc_gicp_params {
+  double transformation_epsilon, rotation_epsilon, max_correspondence_distance, lm_init_lambda_factor;
+  int32_t max_iterations, k_correspondences, regularization, optimizer, lm_max_iterations, num_threads;
+} orc_gicp_params;
+void orc_gicp_default_params(orc_gicp_params* p);
+void* orc_gicp_create(const orc_gicp_params* p);
+void orc_gicp_destroy(void* h);
+void orc_gicp_set_target(void* h, const float* xyz16, int64_t n);
+void orc_gicp_set_source(void* h, const float* xyz16, int64_t n);
+void orc_gicp_align(void* h, const float* guess16, orc_result* out);
+/* pose as a row-major double 4x4 (Eigen::Isometry3d) */
+double orc_gicp_linearize(void* h, const double* T16_rowmajor, double* H36, double* b6);
+double orc_gicp_compute_error(void* h, const double* T16_rowmajor);
+/* covariances: which = 0 source, 1 target; out 9 doubles per point */
+void orc_gicp_covariances(void* h, int32_t which, double* out9);
+void orc_gicp_correspondences(void* h, int32_t* corr, float* sq_dist);
+double orc_fitness_score(const float* target, int64_t nt, const float* source, int64_t ns, const float* T16, double max_range,
+                         double inlier_sq, int64_t* n_used, int64_t* n_inliers);
+void orc_knn(const float* cloud, int64_t n, const float* queries, int64_t m, int32_t k, int32_t* idx, float* d2);
+void orc_se3_exp(const double* a6, double* T16_rowmajor);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,3 +222,106 @@ def sym_eig3(A):
 
 def max_threads() -> int:
     return int(lib().orc_max_threads())
+
+
+GICP_REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
+
+
+class GicpOracle:
+    """CPU restatement of fast_gicp::FastGICP (registrations.cpp:27-36)."""
+
+    def __init__(self, transformation_epsilon=0.01, max_iterations=64, max_correspondence_distance=2.5, k_correspondences=20,
+                 rotation_epsilon=2e-3, regularization="PLANE", optimizer=1, lm_max_iterations=10, lm_init_lambda_factor=1e-9,
+                 num_threads=0, perturbed=False):
+        L = lib(perturbed)
+        self._L = L
+        p = GicpParams()
+        L.orc_gicp_default_params(C.byref(p))
+        p.transformation_epsilon = transformation_epsilon
+        p.max_iterations = max_iterations
+        p.max_correspondence_distance = max_correspondence_distance
+        p.k_correspondences = k_correspondences
+        p.rotation_epsilon = rotation_epsilon
+        p.regularization = GICP_REG[regularization] if isinstance(regularization, str) else int(regularization)
+        p.optimizer = optimizer
+        p.lm_max_iterations = lm_max_iterations
+        p.lm_init_lambda_factor = lm_init_lambda_factor
+        p.num_threads = num_threads
+        self.params = p
+        self._h = C.c_void_p(L.orc_gicp_create(C.byref(p)))
+        self.ns = self.nt = 0
+
+    def __del__(self):
+        try:
+            self._L.orc_gicp_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_target(self, cloud):
+        a, pa = _f32c(cloud)
+        self.nt = a.shape[0]
+        self._L.orc_gicp_set_target(self._h, pa, C.c_int64(a.shape[0]))
+
+    def set_source(self, cloud):
+        a, pa = _f32c(cloud)
+        self.ns = a.shape[0]
+        self._L.orc_gicp_set_source(self._h, pa, C.c_int64(a.shape[0]))
+
+    def align(self, guess=None):
+        g = _colmajor16(np.eye(4) if guess is None else guess)
+        res = Result()
+        self._L.orc_gicp_align(self._h, g.ctypes.data_as(C.POINTER(C.c_float)), C.byref(res))
+        return dict(T=_from_colmajor16(res.T), converged=bool(res.converged), iterations=res.iterations,
+                    evaluations=res.evaluations, score=res.score)
+
+    def linearize(self, T):
+        T, pt = _f64c(np.asarray(T, np.float64))
+        H = np.zeros((6, 6))
+        b = np.zeros(6)
+        e = self._L.orc_gicp_linearize(self._h, pt, H.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)))
+        return e, H, b
+
+    def compute_error(self, T):
+        T, pt = _f64c(np.asarray(T, np.float64))
+        return self._L.orc_gicp_compute_error(self._h, pt)
+
+    def covariances(self, which="source"):
+        n = self.ns if which == "source" else self.nt
+        out = np.zeros((n, 3, 3))
+        self._L.orc_gicp_covariances(self._h, C.c_int32(0 if which == "source" else 1), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def correspondences(self):
+        corr = np.zeros(self.ns, np.int32)
+        sq = np.zeros(self.ns, np.float32)
+        self._L.orc_gicp_correspondences(self._h, corr.ctypes.data_as(C.POINTER(C.c_int32)), sq.ctypes.data_as(C.POINTER(C.c_float)))
+        return corr, sq
+
+
+def fitness_score(target, source, T, max_range=1.7976931348623157e308, inlier_sq=0.25):
+    """pcl::Registration::getFitnessScore + inlier count -> (score, n_used, n_inliers)"""
+    t, pt = _f32c(target)
+    s, ps = _f32c(source)
+    t16 = _colmajor16(T)
+    nu = C.c_int64(0)
+    ni = C.c_int64(0)
+    sc = lib().orc_fitness_score(pt, C.c_int64(t.shape[0]), ps, C.c_int64(s.shape[0]), t16.ctypes.data_as(C.POINTER(C.c_float)),
+                                 C.c_double(max_range), C.c_double(inlier_sq), C.byref(nu), C.byref(ni))
+    return sc, nu.value, ni.value
+
+
+def knn(cloud, queries, k):
+    c, pc = _f32c(cloud)
+    q, pq = _f32c(queries)
+    idx = np.zeros((q.shape[0], k), np.int32)
+    d2 = np.zeros((q.shape[0], k), np.float32)
+    lib().orc_knn(pc, C.c_int64(c.shape[0]), pq, C.c_int64(q.shape[0]), C.c_int32(k), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                  d2.ctypes.data_as(C.POINTER(C.c_float)))
+    return idx, d2
+
+
+def se3_exp(a):
+    a, pa = _f64c(a)
+    T = np.zeros((4, 4))
+    lib().orc_se3_exp(pa, T.ctypes.data_as(C.POINTER(C.c_double)))
+    return T
