@@ -47,7 +47,7 @@ SYMBOLS = [
     "dgs_synchronize", "dgs_set_input_target", "dgs_set_input_source", "dgs_align", "dgs_get_fitness_score",
     "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_align_batch", "dgs_profile_enable",
     "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_get_voxels",
-    "dgs_ndt_get_trajectory",
+    "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize",
 ]
 
 _lib = None
@@ -87,5 +87,7 @@ def load():
     lib.dgs_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_double), C.c_void_p, C.c_void_p]
     lib.dgs_ndt_get_voxels.argtypes = [C.c_void_p, P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dgs_ndt_get_trajectory.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, P(C.c_int32)]
+    lib.dgs_gicp_get_covariances.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.dgs_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, P(C.c_double), C.c_void_p, C.c_void_p]
     _lib = lib
     return lib

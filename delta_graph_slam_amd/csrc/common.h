@@ -82,6 +82,32 @@ struct NdtPair {
   double traj[kTrajCap][6];
 };
 
+// ---- per-pair GICP optimiser state (fast_gicp::LsqRegistration) -------------------------------
+enum GicpPhase : int { GP_LINEARIZE_WAIT = 0, GP_ERROR_WAIT = 1, GP_DONE = 2, GP_PROBE = 3 };
+
+struct GicpSolver {
+  int phase, iteration, evaluations, converged, lm_try, pad;
+  double x0[12];     // current pose, rows 0..2 of the double 4x4 (Eigen::Isometry3d), row-major 3x4
+  double xi[12];     // trial pose delta * x0
+  double delta[12];  // last se3_exp(d)
+  double H[36], b[6], d[6];
+  double y0, yi, lambda, nu;
+};
+
+struct GicpPair {
+  double Teval[12];  // pose of the evaluation in flight
+  int eval_kind;     // 0: update_correspondences + linearize, 1: compute_error on the stored correspondences
+  int active;
+  GicpSolver s;
+  float final_T[16];  // column-major
+};
+
+struct GicpConsts {
+  double trans_eps, rot_eps, lm_init_lambda_factor;
+  float max_corr_sq;  // corr_dist_threshold_^2 as upstream forms it (float)
+  int max_iterations, optimizer, lm_max_iterations, k, regularization;
+};
+
 struct NdtConsts {
   double gauss_d1, gauss_d2;
   double step_size, trans_eps;

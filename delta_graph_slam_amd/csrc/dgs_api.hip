@@ -176,6 +176,9 @@ void dgs_destroy(dgs_handle* h) {
   h->target_bvh.sorted.release(); h->target_bvh.node_lo.release(); h->target_bvh.node_hi.release();
   h->target_bvh.keys.release(); h->target_bvh.keys_alt.release(); h->target_bvh.vals.release(); h->target_bvh.vals_alt.release();
   h->nn_partials.release(); h->scratch_cloud.release();
+  h->source_bvh.sorted.release(); h->source_bvh.node_lo.release(); h->source_bvh.node_hi.release();
+  h->source_bvh.keys.release(); h->source_bvh.keys_alt.release(); h->source_bvh.vals.release(); h->source_bvh.vals_alt.release();
+  h->cov_target.release(); h->cov_source.release(); h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
   for (auto& ep : h->prof.pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -214,6 +217,7 @@ int dgs_set_input_target(dgs_handle* h, const float* xyz16, int64_t n, int32_t o
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_target = false;
   h->target_bvh.valid = false;
+  h->cov_target_valid = false;
   h->nt = n;
   int rc = upload_cloud(h, h->target, xyz16, n, on_device);
   if (rc) return rc;
@@ -230,6 +234,8 @@ int dgs_set_input_source(dgs_handle* h, const float* xyz16, int64_t n, int32_t o
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_source = false;
+  h->source_bvh.valid = false;
+  h->cov_source_valid = false;
   h->ns = n;
   int rc = upload_cloud(h, h->source, xyz16, n, on_device);
   if (rc) return rc;
@@ -261,8 +267,7 @@ int dgs_align(dgs_handle* h, const float* guess16, dgs_result* out, float* align
     const int n = (int)h->ns;
     rc = ndt_align_pairs(h, 1, &src, &n, guess16, out);
   } else {
-    h->err = "FAST_GICP is not built into this library revision";
-    rc = DGS_ERR_UNSUPPORTED;
+    rc = gicp_align(h, guess16, out);
   }
   if (rc != DGS_OK) {
     fail_result(out, guess16, rc);
@@ -353,7 +358,18 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
     h->err = "no input target dataset was given";
     return DGS_ERR_NO_TARGET;
   }
-  if (h->prm.method != DGS_METHOD_NDT) { h->err = "batched FAST_GICP is not built into this library revision"; return DGS_ERR_UNSUPPORTED; }
+  if (h->prm.method != DGS_METHOD_NDT) {
+    // FAST_GICP candidates run one after another on the device (each needs its own source index + covariances)
+    int rc_all = DGS_OK;
+    for (int i = 0; i < n; i++) {
+      if (sizes[i] <= 0 || !sources[i]) { fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_ERR_NO_SOURCE); continue; }
+      int rc = dgs_set_input_source(h, sources[i], sizes[i], on_device);
+      if (rc == DGS_OK) rc = dgs_align(h, guesses16 ? guesses16 + 16 * i : nullptr, &results[i], nullptr, 0);
+      if (rc == DGS_OK && compute_fitness) rc = dgs_get_fitness_score(h, fitness_max_range, &results[i].fitness);
+      if (rc != DGS_OK) { results[i].status = rc; rc_all = rc; }
+    }
+    return (rc_all == DGS_ERR_HIP) ? rc_all : DGS_OK;
+  }
   // stage sources on the device when they come from the host (one contiguous slab)
   std::vector<const float4*> ptrs(n);
   std::vector<int> sz(n);
@@ -455,6 +471,25 @@ int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, doubl
   if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
   if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
   return ndt_probe(h, p6, T16, score, grad6, hess36);
+}
+
+int dgs_gicp_get_covariances(dgs_handle* h, int32_t which, double* cov9) {
+  if (!h || !cov9) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (h->prm.method != DGS_METHOD_GICP) return DGS_ERR_UNSUPPORTED;
+  if (which ? (!h->have_target || h->nt == 0) : (!h->have_source || h->ns == 0)) return which ? DGS_ERR_NO_TARGET : DGS_ERR_NO_SOURCE;
+  return gicp_covariances(h, which, cov9, which ? h->nt : h->ns);
+}
+
+int dgs_gicp_linearize(dgs_handle* h, const double* T16_rowmajor, int32_t error_only, double* error, double* hess36, double* b6) {
+  if (!h || !T16_rowmajor || !error || (!error_only && (!hess36 || !b6))) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (h->prm.method != DGS_METHOD_GICP) return DGS_ERR_UNSUPPORTED;
+  if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
+  if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
+  return gicp_probe(h, T16_rowmajor, error_only, error, hess36, b6);
 }
 
 int dgs_ndt_get_trajectory(dgs_handle* h, int32_t pair, double* poses6, int32_t* len) {

@@ -1,0 +1,642 @@
+// K4 knn_covariance, K5 gicp_correspond, K6 gicp_linearize / gicp_error and the Levenberg-Marquardt driver on the device.
+//
+// Replaces fast_gicp::FastGICP::computeTransformation (on fast_gicp::LsqRegistration), i.e. what
+// registration->align(*aligned, guess) runs at /root/reference/apps/scan_matching_odometry_nodelet.cpp:218 and
+// /root/reference/include/hdl_graph_slam/loop_detector.hpp:145 when registration_method is FAST_GICP (the value every
+// shipped launch file sets; object configured at src/hdl_graph_slam/registrations.cpp:27-36).  Algorithm: SURVEY.md App. B.
+//
+// MI355X design
+//   * No kd-trees: both clouds get the 8-ary Morton AABB index of nn_bvh.hip; k-NN covariances and the per-iteration
+//     1-NN correspondences are searched by 8-lane groups (nn_group.h), exact and bounded by max_correspondence_distance.
+//   * One linearisation = correspond (8 lanes / point) + linearize (1 lane / point, all double: RCR = C_B + R C_A R^T,
+//     3x3 inverse, J = [skew(Tp) | -I], 21 + 6 + 1 sums) with the same wave-DPP -> LDS -> fixed-order partial rows as NDT,
+//     so the sums are bit-reproducible (upstream's per-thread OpenMP partials are not).
+//   * gicp_solve (one wave per registration) runs LM / GN, se3_exp, the rho test and the convergence test on the device
+//     and queues the next evaluation in place: no host round trip per iteration.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "handle.h"
+#include "nn_group.h"
+#include "small_linalg.h"
+#include "solve6.h"
+
+namespace dgs {
+
+// ================================================================================================ K4 covariances
+__device__ void regularize_cov(const double* cov9, int method, double* out6) {
+  double C[9];
+  if (method == DGS_GICP_REG_NONE) {
+    for (int a = 0; a < 9; a++) C[a] = cov9[a];
+  } else if (method == DGS_GICP_REG_FROBENIUS) {
+    const double lambda = 1e-3;
+    double A[9], Ai[9];
+    for (int a = 0; a < 9; a++) A[a] = cov9[a] + ((a % 4 == 0) ? lambda : 0.0);
+    inv3_d(A, Ai);
+    double nrm = 0;
+    for (int a = 0; a < 9; a++) nrm += Ai[a] * Ai[a];
+    nrm = sqrt(nrm);
+    for (int a = 0; a < 9; a++) Ai[a] /= nrm;
+    inv3_d(Ai, C);
+  } else {
+    // JacobiSVD of a symmetric PSD 3x3 == eigen-decomposition, singular values descending
+    double ev[3], V[9];
+    sym_eig3_d(cov9, ev, V);
+    const double sv[3] = {fabs(ev[2]), fabs(ev[1]), fabs(ev[0])};
+    double vals[3];
+    if (method == DGS_GICP_REG_PLANE) {
+      vals[0] = 1; vals[1] = 1; vals[2] = 1e-3;
+    } else if (method == DGS_GICP_REG_MIN_EIG) {
+      for (int a = 0; a < 3; a++) vals[a] = fmax(sv[a], 1e-3);
+    } else {
+      for (int a = 0; a < 3; a++) vals[a] = fmax(sv[a] / sv[0], 1e-3);
+    }
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) C[r * 3 + c] = V[r * 3 + 2] * vals[0] * V[c * 3 + 2] + V[r * 3 + 1] * vals[1] * V[c * 3 + 1] + V[r * 3 + 0] * vals[2] * V[c * 3 + 0];
+  }
+  out6[0] = C[0]; out6[1] = C[1]; out6[2] = C[2]; out6[3] = C[4]; out6[4] = C[5]; out6[5] = C[8];
+}
+
+// FastGICP::calculate_covariances: exact k-NN of every point in its own cloud, covariance of the neighbours, regularised
+__global__ __launch_bounds__(kBlock) void gicp_covariance_kernel(const BvhView b, const float4* __restrict__ pts, int n, int k, int method,
+                                                                 double* __restrict__ cov6) {
+  const int sub = threadIdx.x & 7;
+  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 3;
+  const bool alive = i < n;
+  const float4 q = alive ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  KnnList L;
+  knn_query_group(b, q.x, q.y, q.z, alive, k, L);
+  if (!alive) return;
+  // neighbours of this lane (slots r * 8 + sub < k); slots that found nothing are zero columns, as upstream's matrix
+  double px[kKnnSlots], py[kKnnSlots], pz[kKnnSlots];
+  bool use[kKnnSlots];
+  double sx = 0, sy = 0, sz = 0;
+#pragma unroll
+  for (int r = 0; r < kKnnSlots; r++) {
+    use[r] = (r * 8 + sub) < k;
+    const bool found = use[r] && L.d[r] < INFINITY;
+    const float4 p = found ? pts[L.id[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    px[r] = p.x; py[r] = p.y; pz[r] = p.z;
+    if (use[r]) { sx += px[r]; sy += py[r]; sz += pz[r]; }
+  }
+  const double kk = (double)k;
+  const double mx = group8_sum_f64(sx) / kk, my = group8_sum_f64(sy) / kk, mz = group8_sum_f64(sz) / kk;
+  double c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < kKnnSlots; r++) {
+    if (use[r]) {
+      const double dx = px[r] - mx, dy = py[r] - my, dz = pz[r] - mz;
+      c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; a++) c[a] = group8_sum_f64(c[a]) / kk;
+  if (sub == 0) {
+    const double cov9[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+    double out6[6];
+    regularize_cov(cov9, method, out6);
+#pragma unroll
+    for (int a = 0; a < 6; a++) cov6[(size_t)i * 6 + a] = out6[a];
+  }
+}
+
+// ================================================================================================ K5 correspondences
+// FastGICP::update_correspondences, search part: x' = float(T) * p in float, exact 1-NN in the target, accepted iff
+// d^2 < corr_dist_threshold^2
+__global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b, const float4* __restrict__ src, int n,
+                                                                 const GicpPair* __restrict__ pairs, float max_sq, int* __restrict__ corr,
+                                                                 float* __restrict__ corr_sq) {
+  const GicpPair& st = pairs[0];
+  if (!st.active || st.eval_kind != 0) return;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = (float)st.Teval[k];
+  const int sub = threadIdx.x & 7;
+  constexpr int QPB = kBlock / 8;
+  const int sweeps = (n + gridDim.x * QPB - 1) / (gridDim.x * QPB);
+  for (int sw = 0; sw < sweeps; sw++) {
+    const int i = (sw * gridDim.x + blockIdx.x) * QPB + (threadIdx.x >> 3);
+    const bool alive = i < n;
+    const float4 p = alive ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float x = affine_row_rn(T[0], T[1], T[2], T[3], p.x, p.y, p.z);
+    const float y = affine_row_rn(T[4], T[5], T[6], T[7], p.x, p.y, p.z);
+    const float z = affine_row_rn(T[8], T[9], T[10], T[11], p.x, p.y, p.z);
+    float best;
+    int bi;
+    nn_query_group(b, x, y, z, alive, max_sq, best, bi);  // nothing farther than the threshold can be a correspondence
+    if (alive && sub == 0) {
+      const bool ok = (bi != 0x7FFFFFFF) && (best < max_sq);
+      corr[i] = ok ? bi : -1;
+      corr_sq[i] = best;
+    }
+  }
+}
+
+// ================================================================================================ K6 linearize / error
+__global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const float4* __restrict__ src, int n, const float4* __restrict__ tgt,
+                                                                const double* __restrict__ cov_s, const double* __restrict__ cov_t,
+                                                                const int* __restrict__ corr, double* __restrict__ mahal,
+                                                                const GicpPair* __restrict__ pairs, double* __restrict__ partials,
+                                                                const int nblocks) {
+  const GicpPair& st = pairs[0];
+  if (!st.active) return;
+  const bool full = st.eval_kind == 0;
+  double T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st.Teval[k];
+  double acc[kAccum];
+#pragma unroll
+  for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
+
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += nblocks * kBlock) {
+    const int j = corr[i];
+    if (j < 0) continue;
+    const float4 pa = src[i], pb = tgt[j];
+    double M[6];
+    if (full) {
+      // RCR = C_B + R C_A R^T, Mahalanobis = RCR^-1 (3x3 block of upstream's 4x4)
+      const double* CA = cov_s + (size_t)i * 6;
+      const double* CB = cov_t + (size_t)j * 6;
+      const double a0 = CA[0], a1 = CA[1], a2 = CA[2], a3 = CA[3], a4 = CA[4], a5 = CA[5];
+      double RC[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const double r0 = T[r * 4 + 0], r1 = T[r * 4 + 1], r2 = T[r * 4 + 2];
+        RC[r * 3 + 0] = r0 * a0 + r1 * a1 + r2 * a2;
+        RC[r * 3 + 1] = r0 * a1 + r1 * a3 + r2 * a4;
+        RC[r * 3 + 2] = r0 * a2 + r1 * a4 + r2 * a5;
+      }
+      double S[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) S[r * 3 + c] = RC[r * 3 + 0] * T[c * 4 + 0] + RC[r * 3 + 1] * T[c * 4 + 1] + RC[r * 3 + 2] * T[c * 4 + 2];
+      S[0] += CB[0]; S[1] += CB[1]; S[2] += CB[2]; S[3] += CB[1]; S[4] += CB[3]; S[5] += CB[4]; S[6] += CB[2]; S[7] += CB[4]; S[8] += CB[5];
+      double Mi[9];
+      inv3_d(S, Mi);
+      M[0] = Mi[0]; M[1] = Mi[1]; M[2] = Mi[2]; M[3] = Mi[4]; M[4] = Mi[5]; M[5] = Mi[8];
+      double* mo = mahal + (size_t)i * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) mo[k] = M[k];
+    } else {
+      const double* mo = mahal + (size_t)i * 6;
+#pragma unroll
+      for (int k = 0; k < 6; k++) M[k] = mo[k];
+    }
+    const double ax = pa.x, ay = pa.y, az = pa.z;
+    const double t0 = T[0] * ax + T[1] * ay + T[2] * az + T[3];
+    const double t1 = T[4] * ax + T[5] * ay + T[6] * az + T[7];
+    const double t2 = T[8] * ax + T[9] * ay + T[10] * az + T[11];
+    const double e0 = (double)pb.x - t0, e1 = (double)pb.y - t1, e2 = (double)pb.z - t2;
+    const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2;
+    const double m1 = M[1] * e0 + M[3] * e1 + M[4] * e2;
+    const double m2 = M[2] * e0 + M[4] * e1 + M[5] * e2;
+    acc[0] += e0 * m0 + e1 * m1 + e2 * m2;
+    if (full) {
+      // J = [ skew(t) | -I ];  b = J^T M e = [ (Me) x t ; -Me ]
+      acc[1] += m1 * t2 - m2 * t1;
+      acc[2] += m2 * t0 - m0 * t2;
+      acc[3] += m0 * t1 - m1 * t0;
+      acc[4] += -m0;
+      acc[5] += -m1;
+      acc[6] += -m2;
+      // H = J^T M J = [[S^T M S, -S^T M], [-M S, M]] with S = skew(t):  G = M S (3x3), then S^T G and -G^T
+      const double Mf[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
+      const double Sk[9] = {0, -t2, t1, t2, 0, -t0, -t1, t0, 0};
+      double G[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) G[r * 3 + c] = Mf[r * 3 + 0] * Sk[0 * 3 + c] + Mf[r * 3 + 1] * Sk[1 * 3 + c] + Mf[r * 3 + 2] * Sk[2 * 3 + c];
+      // rr block: (S^T G)(r,c) = sum_k S(k,r) G(k,c)
+      double Hrr[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Hrr[r * 3 + c] = Sk[0 * 3 + r] * G[0 * 3 + c] + Sk[1 * 3 + r] * G[1 * 3 + c] + Sk[2 * 3 + r] * G[2 * 3 + c];
+      // rt block: (-S^T M)(r,c) = -sum_k S(k,r) M(k,c) = -(G^T)(r,c) ... G = M S  =>  (M S)^T = S^T M  (M symmetric)
+      // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+      acc[7] += Hrr[0]; acc[8] += Hrr[1]; acc[9] += Hrr[2]; acc[10] += -G[0 * 3 + 0]; acc[11] += -G[1 * 3 + 0]; acc[12] += -G[2 * 3 + 0];
+      acc[13] += Hrr[4]; acc[14] += Hrr[5]; acc[15] += -G[0 * 3 + 1]; acc[16] += -G[1 * 3 + 1]; acc[17] += -G[2 * 3 + 1];
+      acc[18] += Hrr[8]; acc[19] += -G[0 * 3 + 2]; acc[20] += -G[1 * 3 + 2]; acc[21] += -G[2 * 3 + 2];
+      acc[22] += M[0]; acc[23] += M[1]; acc[24] += M[2];
+      acc[25] += M[3]; acc[26] += M[4];
+      acc[27] += M[5];
+    }
+  }
+  __shared__ double sm[kBlock / kWave][kAccumPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kAccum; k++) {
+    const double v = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) sm[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumPad) {
+    double v = 0.0;
+    if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    partials[(size_t)blockIdx.x * kAccumPad + threadIdx.x] = v;
+  }
+}
+
+// ================================================================================================ solver
+// so3_exp / se3_exp of fast_gicp (quaternion form); out = rows 0..2 of the 4x4, row-major 3x4
+__device__ void se3_exp_dev(const double* a, double* T) {
+  const double wx = a[0], wy = a[1], wz = a[2];
+  const double theta_sq = wx * wx + wy * wy + wz * wz;
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double tq = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
+  } else {
+    const double theta = sqrt(theta_sq), half = 0.5 * theta;
+    imag = sin(half) / theta;
+    real = cos(half);
+  }
+  const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+  const double theta = sqrt(theta_sq);
+  double V[9];
+  if (theta < 1e-10) {
+    for (int i = 0; i < 9; i++) V[i] = R[i];
+  } else {
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3 + 0] * O[0 * 3 + c] + O[r * 3 + 1] * O[1 * 3 + c] + O[r * 3 + 2] * O[2 * 3 + c];
+    const double c1 = (1.0 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+  }
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) T[r * 4 + c] = R[r * 3 + c];
+    T[r * 4 + 3] = V[r * 3 + 0] * a[3] + V[r * 3 + 1] * a[4] + V[r * 3 + 2] * a[5];
+  }
+}
+
+__device__ inline void iso_mul(const double* A, const double* B, double* C) {  // 3x4 isometries, C = A * B
+  double T[12];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 4; c++) T[r * 4 + c] = A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c] + A[r * 4 + 2] * B[2 * 4 + c];
+    T[r * 4 + 3] += A[r * 4 + 3];
+  }
+  for (int k = 0; k < 12; k++) C[k] = T[k];
+}
+
+__device__ inline bool gicp_is_converged(const double* delta, const GicpConsts& c) {
+  double rmax = 0, tmax = 0;
+  for (int r = 0; r < 3; r++) {
+    for (int cc = 0; cc < 3; cc++) rmax = fmax(rmax, fabs(delta[r * 4 + cc] - (r == cc ? 1.0 : 0.0)) / c.rot_eps);
+    tmax = fmax(tmax, fabs(delta[r * 4 + 3]) / c.trans_eps);
+  }
+  return fmax(rmax, tmax) < 1;
+}
+
+__device__ void gicp_queue(GicpPair* st, const double* T, int kind, bool writer) {
+  if (writer) {
+    for (int k = 0; k < 12; k++) st->Teval[k] = T[k];
+    st->eval_kind = kind;
+  }
+}
+
+__device__ void gicp_try_lm(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
+  double Hl[36], nb[6];
+  for (int k = 0; k < 36; k++) Hl[k] = s.H[k];
+  for (int k = 0; k < 6; k++) { Hl[k * 6 + k] += s.lambda; nb[k] = -s.b[k]; }
+  solve6_wave(Hl, nb, s.d);
+  se3_exp_dev(s.d, s.delta);
+  iso_mul(s.delta, s.x0, s.xi);
+  gicp_queue(st, s.xi, 1, writer);
+  s.phase = GP_ERROR_WAIT;
+}
+
+// after a successful optimisation step: convergence test of LsqRegistration::computeTransformation
+__device__ void gicp_after_step(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
+  const bool conv = gicp_is_converged(s.delta, c);
+  s.converged = conv ? 1 : 0;
+  if (!conv && s.iteration + 1 < c.max_iterations) {
+    s.iteration++;
+    gicp_queue(st, s.x0, 0, writer);
+    s.phase = GP_LINEARIZE_WAIT;
+  } else {
+    s.phase = GP_DONE;
+  }
+}
+
+__device__ void gicp_advance(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
+  s.evaluations++;
+  if (s.phase == GP_PROBE) {
+    s.phase = GP_DONE;
+    return;
+  }
+  if (s.phase == GP_LINEARIZE_WAIT) {
+    if (c.optimizer == DGS_GICP_OPT_GAUSS_NEWTON) {
+      double nb[6];
+      for (int k = 0; k < 6; k++) nb[k] = -s.b[k];
+      solve6_wave(s.H, nb, s.d);
+      se3_exp_dev(s.d, s.delta);
+      iso_mul(s.delta, s.x0, s.x0);
+      gicp_after_step(st, s, c, writer);
+      return;
+    }
+    if (s.lambda < 0.0) {
+      double m = 0;
+      for (int k = 0; k < 6; k++) m = fmax(m, fabs(s.H[k * 6 + k]));
+      s.lambda = c.lm_init_lambda_factor * m;
+    }
+    s.nu = 2.0;
+    s.lm_try = 0;
+    gicp_try_lm(st, s, c, writer);
+    return;
+  }
+  if (s.phase == GP_ERROR_WAIT) {
+    double denom = 0;
+    for (int k = 0; k < 6; k++) denom += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
+    const double rho = (s.y0 - s.yi) / denom;
+    if (rho < 0) {
+      if (gicp_is_converged(s.delta, c)) {  // step_lm returns true without moving x0
+        gicp_after_step(st, s, c, writer);
+        return;
+      }
+      s.lambda = s.nu * s.lambda;
+      s.nu = 2 * s.nu;
+      s.lm_try++;
+      if (s.lm_try < c.lm_max_iterations) {
+        gicp_try_lm(st, s, c, writer);
+      } else {  // "lm not converged!!": the outer loop breaks, converged_ stays false
+        s.converged = 0;
+        s.phase = GP_DONE;
+      }
+      return;
+    }
+    for (int k = 0; k < 12; k++) s.x0[k] = s.xi[k];
+    const double t = 2 * rho - 1;
+    s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
+    s.y0 = s.yi;
+    gicp_after_step(st, s, c, writer);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gicp_solve_kernel(GicpPair* __restrict__ pairs, const double* __restrict__ partials, const int nblocks,
+                                                            const GicpConsts c, int* __restrict__ done_counter) {
+  GicpPair* st = pairs;
+  if (!st->active) return;
+  __shared__ double sm[kBlock / kAccumPad][kAccumPad];
+  const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
+  constexpr int G = kBlock / kAccumPad;
+  double v = 0.0;
+  for (int b = grp; b < nblocks; b += G) v += partials[(size_t)b * kAccumPad + col];
+  sm[grp][col] = v;
+  __syncthreads();
+  __shared__ double tot[kAccumPad];
+  if (threadIdx.x < kAccumPad) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  const bool writer = threadIdx.x == 0;
+  GicpSolver s = st->s;
+  if (st->eval_kind == 0) {
+    s.y0 = tot[0];
+    for (int k = 0; k < 6; k++) s.b[k] = tot[1 + k];
+    int q = 7;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        s.H[i * 6 + j] = tot[q];
+        s.H[j * 6 + i] = tot[q];
+        q++;
+      }
+  } else {
+    s.yi = tot[0];
+  }
+  gicp_advance(st, s, c, writer);
+  if (writer) {
+    st->s = s;
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 4; cc++) st->final_T[cc * 4 + r] = (float)s.x0[r * 4 + cc];
+    st->final_T[3] = st->final_T[7] = st->final_T[11] = 0.f;
+    st->final_T[15] = 1.f;
+    if (s.phase == GP_DONE) {
+      st->active = 0;
+      atomicAdd(done_counter, 1);
+    }
+  }
+}
+
+struct GicpInit {
+  double x0[12];
+  int probe_kind;  // -1: normal align; 0 / 1: probe a linearisation / an error evaluation
+  int pad;
+};
+
+__global__ void gicp_init_kernel(GicpPair* __restrict__ pairs, const GicpInit* __restrict__ init) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  GicpPair* st = pairs;
+  GicpSolver s;
+  s.phase = (init->probe_kind >= 0) ? GP_PROBE : GP_LINEARIZE_WAIT;
+  s.iteration = 0;
+  s.evaluations = 0;
+  s.converged = 0;
+  s.lm_try = 0;
+  s.pad = 0;
+  for (int k = 0; k < 12; k++) { s.x0[k] = init->x0[k]; s.xi[k] = init->x0[k]; s.delta[k] = (k % 5 == 0) ? 1.0 : 0.0; st->Teval[k] = init->x0[k]; }
+  for (int k = 0; k < 36; k++) s.H[k] = 0;
+  for (int k = 0; k < 6; k++) { s.b[k] = 0; s.d[k] = 0; }
+  s.y0 = s.yi = 0;
+  s.lambda = -1.0;
+  s.nu = 2.0;
+  st->s = s;
+  st->eval_kind = (init->probe_kind > 0) ? 1 : 0;
+  st->active = 1;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) st->final_T[c * 4 + r] = (float)init->x0[r * 4 + c];
+  st->final_T[3] = st->final_T[7] = st->final_T[11] = 0.f;
+  st->final_T[15] = 1.f;
+}
+
+// ================================================================================================ host side
+static void fill_gconsts(dgs_handle* h) {
+  GicpConsts& c = h->gconsts;
+  const dgs_params& p = h->prm;
+  c.trans_eps = p.transformation_epsilon;
+  c.rot_eps = p.gicp_rotation_epsilon;
+  c.lm_init_lambda_factor = p.gicp_lm_init_lambda_factor;
+  const float dmax = (float)p.gicp_max_correspondence_distance;
+  c.max_corr_sq = dmax * dmax;
+  c.max_iterations = p.maximum_iterations;
+  c.optimizer = p.gicp_optimizer;
+  c.lm_max_iterations = p.gicp_lm_max_iterations;
+  c.k = p.gicp_correspondence_randomness;
+  c.regularization = p.gicp_regularization;
+}
+
+static int ensure_covariance(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n, DevBuf<double>& cov, bool& valid) {
+  if (valid) return DGS_OK;
+  if (h->gconsts.k > kKnnMax) {
+    h->err = "reg_correspondence_randomness > 32 is not supported by the HIP k-NN";
+    return DGS_ERR_UNSUPPORTED;
+  }
+  if (!bvh.valid) {
+    int rc = bvh_build(h, bvh, pts, n);
+    if (rc) return rc;
+  }
+  DGS_HIP_TRY(h, cov.reserve((size_t)n * 6));
+  const BvhView v = make_bvh_view(bvh);
+  int slot = prof_begin(h, DGS_K_GICP_COVARIANCE);
+  hipLaunchKernelGGL(gicp_covariance_kernel, dim3((unsigned)(((int64_t)n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, pts, (int)n, h->gconsts.k,
+                     h->gconsts.regularization, cov.ptr);
+  prof_end(h, DGS_K_GICP_COVARIANCE, slot);
+  DGS_HIP_TRY(h, hipGetLastError());
+  valid = true;
+  return DGS_OK;
+}
+
+static int gicp_prepare(dgs_handle* h) {
+  fill_gconsts(h);
+  int rc = ensure_covariance(h, h->source_bvh, h->source.ptr, h->ns, h->cov_source, h->cov_source_valid);
+  if (rc) return rc;
+  rc = ensure_covariance(h, h->target_bvh, h->target.ptr, h->nt, h->cov_target, h->cov_target_valid);
+  if (rc) return rc;
+  DGS_HIP_TRY(h, h->corr.reserve(h->ns));
+  DGS_HIP_TRY(h, h->corr_sq.reserve(h->ns));
+  DGS_HIP_TRY(h, h->mahal.reserve((size_t)h->ns * 6));
+  DGS_HIP_TRY(h, h->gpairs.reserve(1));
+  DGS_HIP_TRY(h, h->inits.reserve(2));
+  DGS_HIP_TRY(h, h->done_counter.reserve(16));
+  return DGS_OK;
+}
+
+static int gicp_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, 512)); }
+
+static void gicp_launch_round(dgs_handle* h, int nblocks) {
+  const BvhView v = make_bvh_view(h->target_bvh);
+  const int n = (int)h->ns;
+  int slot = prof_begin(h, DGS_K_NN_SEARCH);
+  const int cblocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)n * 8 + kBlock - 1) / kBlock, 4096));
+  hipLaunchKernelGGL(gicp_correspond_kernel, dim3(cblocks), dim3(kBlock), 0, h->stream, v, h->source.ptr, n, h->gpairs.ptr, h->gconsts.max_corr_sq,
+                     h->corr.ptr, h->corr_sq.ptr);
+  prof_end(h, DGS_K_NN_SEARCH, slot);
+  slot = prof_begin(h, DGS_K_GICP_LINEARIZE);
+  hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblocks), dim3(kBlock), 0, h->stream, h->source.ptr, n, h->target.ptr, h->cov_source.ptr,
+                     h->cov_target.ptr, h->corr.ptr, h->mahal.ptr, h->gpairs.ptr, h->partials.ptr, nblocks);
+  prof_end(h, DGS_K_GICP_LINEARIZE, slot);
+  hipLaunchKernelGGL(gicp_solve_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, nblocks, h->gconsts, h->done_counter.ptr);
+}
+
+static int gicp_start(dgs_handle* h, const double* x0_rows, int probe_kind, int* nblocks_out) {
+  hipStream_t st = h->stream;
+  int rc = gicp_prepare(h);
+  if (rc) return rc;
+  const int nblocks = gicp_blocks(h->ns);
+  *nblocks_out = nblocks;
+  DGS_HIP_TRY(h, h->partials.reserve((size_t)nblocks * kAccumPad + 64));
+  if (ensure_pinned(h, 8192 + sizeof(GicpPair)) != DGS_OK) return DGS_ERR_HIP;
+  GicpInit* hin = reinterpret_cast<GicpInit*>(reinterpret_cast<char*>(h->pinned) + 1024);
+  for (int k = 0; k < 12; k++) hin->x0[k] = x0_rows[k];
+  hin->probe_kind = probe_kind;
+  hin->pad = 0;
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, hin, sizeof(GicpInit), hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->done_counter.ptr, 0, 16 * sizeof(int), st));
+  hipLaunchKernelGGL(gicp_init_kernel, dim3(1), dim3(64), 0, st, h->gpairs.ptr, reinterpret_cast<const GicpInit*>(h->inits.ptr));
+  return DGS_OK;
+}
+
+int gicp_align(dgs_handle* h, const float* guess16, dgs_result* out) {
+  hipStream_t st = h->stream;
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const float* G = guess16 ? guess16 : ident;
+  double x0[12];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) x0[r * 4 + c] = (double)G[c * 4 + r];  // Eigen::Isometry3d(guess.cast<double>())
+  int nblocks = 1;
+  int rc = gicp_start(h, x0, -1, &nblocks);
+  if (rc) return rc;
+
+  volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);
+  flags[0] = flags[1] = 0;
+  hipEvent_t ev[2];
+  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  const long max_rounds = (long)h->prm.maximum_iterations * (h->prm.gicp_lm_max_iterations + 1) + 4;
+  const int chunk = 4;
+  long queued = 0;
+  auto enqueue_chunk = [&](int slot) -> int {
+    for (int e = 0; e < chunk; e++) gicp_launch_round(h, nblocks);
+    queued += chunk;
+    DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+    DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
+    return DGS_OK;
+  };
+  int cur = 0;
+  rc = enqueue_chunk(0);
+  while (rc == DGS_OK) {
+    const bool more = queued < max_rounds;
+    if (more) rc = enqueue_chunk(cur ^ 1);
+    if (rc != DGS_OK) break;
+    hipError_t e = hipEventSynchronize(ev[cur]);
+    if (e != hipSuccess) { h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; break; }
+    if (flags[cur] >= 1) break;
+    if (!more) break;
+    cur ^= 1;
+  }
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  if (rc != DGS_OK) return rc;
+  GicpPair* hp = reinterpret_cast<GicpPair*>(reinterpret_cast<char*>(h->pinned) + 4096);
+  DGS_HIP_TRY(h, hipMemcpyAsync(hp, h->gpairs.ptr, sizeof(GicpPair), hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipStreamSynchronize(st));
+  DGS_HIP_TRY(h, hipGetLastError());
+  std::memcpy(out->final_transformation, hp->final_T, sizeof(float) * 16);
+  out->converged = (hp->s.phase == GP_DONE) ? hp->s.converged : 0;
+  out->iterations = hp->s.iteration;
+  out->evaluations = hp->s.evaluations;
+  out->status = DGS_OK;
+  out->score = hp->s.y0;
+  out->fitness = NAN;
+  h->last_evaluations = hp->s.evaluations;
+  return DGS_OK;
+}
+
+// Test hook: regularised covariances (9 doubles per point, row-major) of the source (which = 0) or target (1) cloud.
+int gicp_covariances(dgs_handle* h, int which, double* host_out9, int64_t n) {
+  fill_gconsts(h);
+  int rc = which ? ensure_covariance(h, h->target_bvh, h->target.ptr, h->nt, h->cov_target, h->cov_target_valid)
+                 : ensure_covariance(h, h->source_bvh, h->source.ptr, h->ns, h->cov_source, h->cov_source_valid);
+  if (rc) return rc;
+  std::vector<double> c6((size_t)n * 6);
+  DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  DGS_HIP_TRY(h, hipMemcpy(c6.data(), which ? h->cov_target.ptr : h->cov_source.ptr, c6.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; i++) {
+    const double* c = c6.data() + i * 6;
+    double* o = host_out9 + i * 9;
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[1]; o[4] = c[3]; o[5] = c[4]; o[6] = c[2]; o[7] = c[4]; o[8] = c[5];
+  }
+  return DGS_OK;
+}
+
+// Test hook: one linearize (error_only = 0: fresh correspondences at T) or compute_error (1: stored correspondences).
+int gicp_probe(dgs_handle* h, const double* T16, int error_only, double* err, double* H36, double* b6) {
+  hipStream_t st = h->stream;
+  int nblocks = 1;
+  int rc = gicp_start(h, T16, error_only ? 1 : 0, &nblocks);
+  if (rc) return rc;
+  gicp_launch_round(h, nblocks);
+  GicpPair* hp = reinterpret_cast<GicpPair*>(reinterpret_cast<char*>(h->pinned) + 4096);
+  DGS_HIP_TRY(h, hipMemcpyAsync(hp, h->gpairs.ptr, sizeof(GicpPair), hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipStreamSynchronize(st));
+  DGS_HIP_TRY(h, hipGetLastError());
+  *err = error_only ? hp->s.yi : hp->s.y0;
+  if (!error_only) {
+    for (int k = 0; k < 36; k++) H36[k] = hp->s.H[k];
+    for (int k = 0; k < 6; k++) b6[k] = hp->s.b[k];
+  }
+  return DGS_OK;
+}
+
+}  // namespace dgs

@@ -86,6 +86,16 @@ struct dgs_handle {
   dgs::DevBuf<double> nn_partials;
   dgs::DevBuf<float4> scratch_cloud;
 
+  // ---- GICP (fast_gicp::FastGICP): k-NN covariances of both clouds, correspondences, Mahalanobis matrices
+  dgs::Bvh source_bvh;
+  dgs::DevBuf<double> cov_target, cov_source;  // 6 doubles per point: xx, xy, xz, yy, yz, zz
+  bool cov_target_valid = false, cov_source_valid = false;
+  dgs::DevBuf<int> corr;
+  dgs::DevBuf<float> corr_sq;
+  dgs::DevBuf<double> mahal;                   // 6 doubles per source point
+  dgs::DevBuf<dgs::GicpPair> gpairs;
+  dgs::GicpConsts gconsts{};
+
   dgs::Profiler prof;
 };
 
@@ -99,6 +109,7 @@ int ensure_pinned(dgs_handle* h, size_t bytes);
 // ndt_voxel.hip
 int ndt_build_target(dgs_handle* h);
 int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]);
+int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6);
 // ndt_align.hip
 int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs_host, const int* sizes_host,
                     const float* guesses16, dgs_result* results);
@@ -112,6 +123,10 @@ int nn_fitness(dgs_handle* h, const float4* src, int64_t n, const float* T16, do
 int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
+// gicp.hip
+int gicp_align(dgs_handle* h, const float* guess16, dgs_result* out);
+int gicp_covariances(dgs_handle* h, int which, double* host_out6, int64_t n);
+int gicp_probe(dgs_handle* h, const double* T16_rowmajor, int error_only, double* err, double* H36, double* b6);
 // transform
 int transform_cloud(dgs_handle* h, const float4* in, float4* out, int64_t n, const float* T16_colmajor_host);
 

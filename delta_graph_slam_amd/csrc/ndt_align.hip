@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "handle.h"
+#include "solve6.h"
 
 namespace dgs {
 
@@ -212,84 +213,6 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
 }
 
 // ================================================================================================ solver
-// 6x6 solve by Gauss-Jordan elimination with row pivoting, one matrix element per lane (lanes 0..41 hold [A | b]);
-// every value that steers control flow is wave-uniform.  *rcond receives min|pivot| / max|pivot|.
-__device__ void gj_solve6_wave(const double* A, const double* b, double* x, double* rcond) {
-  const int lane = threadIdx.x & 63;
-  const int i = (lane < 42) ? lane / 7 : 0, j = (lane < 42) ? lane % 7 : 0;
-  double a = 0.0;
-#pragma unroll
-  for (int r = 0; r < 6; r++)
-#pragma unroll
-    for (int c = 0; c < 7; c++)
-      if (lane == r * 7 + c) a = (c < 6) ? A[r * 6 + c] : b[r];
-  double pmax = 0.0, pmin = DBL_MAX;
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    int best_r = k;
-    double best_v = -1.0;
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const double v = fabs(__shfl(a, r * 7 + k, 64));
-      if (r >= k && v > best_v) { best_v = v; best_r = r; }
-    }
-    const int src = (i == k) ? best_r * 7 + j : ((i == best_r) ? k * 7 + j : lane);
-    a = __shfl(a, src, 64);
-    const double piv = __shfl(a, k * 7 + k, 64);
-    pmax = fmax(pmax, fabs(piv));
-    pmin = fmin(pmin, fabs(piv));
-    const double rowk = __shfl(a, k * 7 + j, 64);
-    const double colk = __shfl(a, i * 7 + k, 64);
-    if (piv != 0.0) a = (i == k) ? a / piv : a - colk * (rowk / piv);
-  }
-#pragma unroll
-  for (int r = 0; r < 6; r++) x[r] = __shfl(a, r * 7 + 6, 64);
-  *rcond = (pmax > 0) ? pmin / pmax : 0.0;
-}
-
-// Pseudo-inverse solve through a one-sided Jacobi SVD with Eigen::JacobiSVD's default rank threshold
-// (6 * eps * s_max).  Slow path: only taken when the elimination above meets a (numerically) singular Hessian.
-__device__ __noinline__ void svd_solve6_dev(const double* A, const double* b, double* x) {
-  double U[36], V[36];
-  for (int i = 0; i < 36; i++) { U[i] = A[i]; V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
-  for (int sweep = 0; sweep < 40; sweep++) {
-    bool rotated = false;
-    for (int p = 0; p < 5; p++)
-      for (int q = p + 1; q < 6; q++) {
-        double al = 0, be = 0, ga = 0;
-        for (int k = 0; k < 6; k++) { al += U[k * 6 + p] * U[k * 6 + p]; be += U[k * 6 + q] * U[k * 6 + q]; ga += U[k * 6 + p] * U[k * 6 + q]; }
-        if (ga == 0.0 || fabs(ga) <= 4e-16 * sqrt(al * be)) continue;
-        rotated = true;
-        const double ze = (be - al) / (2.0 * ga);
-        const double t = (ze >= 0 ? 1.0 : -1.0) / (fabs(ze) + sqrt(1.0 + ze * ze));
-        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-        for (int k = 0; k < 6; k++) {
-          const double up = U[k * 6 + p], uq = U[k * 6 + q];
-          U[k * 6 + p] = c * up - s * uq; U[k * 6 + q] = s * up + c * uq;
-          const double vp = V[k * 6 + p], vq = V[k * 6 + q];
-          V[k * 6 + p] = c * vp - s * vq; V[k * 6 + q] = s * vp + c * vq;
-        }
-      }
-    if (!rotated) break;
-  }
-  double sv[6], smax = 0;
-  for (int j = 0; j < 6; j++) {
-    double s2 = 0;
-    for (int k = 0; k < 6; k++) s2 += U[k * 6 + j] * U[k * 6 + j];
-    sv[j] = sqrt(s2);
-    smax = fmax(smax, sv[j]);
-  }
-  const double thr = fmax(smax * 6.0 * DBL_EPSILON, DBL_MIN);
-  for (int i = 0; i < 6; i++) x[i] = 0.0;
-  for (int j = 0; j < 6; j++) {
-    if (!(sv[j] > thr)) continue;
-    double ub = 0;
-    for (int k = 0; k < 6; k++) ub += U[k * 6 + j] * b[k];
-    const double coef = ub / (sv[j] * sv[j]);
-    for (int i = 0; i < 6; i++) x[i] += V[i * 6 + j] * coef;
-  }
-}
-
 // float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap),
 // written to the pair's HBM record by lane 0 (`writer`); every lane computes the same values.
 __device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, const double* x, int need_hessian, bool write_T, bool writer) {

@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "handle.h"
+#include "small_linalg.h"
 
 namespace dgs {
 
@@ -48,23 +49,42 @@ __global__ __launch_bounds__(kBlock) void minmax_kernel(const float4* __restrict
 }
 
 __global__ void minmax_final_kernel(const float* __restrict__ partial, int nblocks, float* __restrict__ out6) {
-  const int t = threadIdx.x;
-  if (t < 6) {
-    float v = partial[t];
-    for (int b = 1; b < nblocks; b++) v = (t < 3) ? fminf(v, partial[b * 6 + t]) : fmaxf(v, partial[b * 6 + t]);
-    out6[t] = v;
+  // one wave: lane l folds blocks l, l+64, ... then a shuffle tree; min for columns 0..2, max for 3..5
+  const int lane = threadIdx.x;
+  float v[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int b = lane; b < nblocks; b += 64)
+    for (int a = 0; a < 6; a++) v[a] = (a < 3) ? fminf(v[a], partial[b * 6 + a]) : fmaxf(v[a], partial[b * 6 + a]);
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float o = __shfl_down(v[a], off, 64);
+      v[a] = (a < 3) ? fminf(v[a], o) : fmaxf(v[a], o);
+    }
   }
+  if (lane == 0)
+    for (int a = 0; a < 6; a++) out6[a] = v[a];
+}
+
+// AABB of the finite points of a device cloud, left on the device (6 floats: min xyz, max xyz); no synchronisation.
+int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6) {
+  hipStream_t st = h->stream;
+  const int mm_blocks = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, 256);
+  DGS_HIP_TRY(h, h->minmax_partial.reserve((size_t)512 * 6 + 8));
+  float* d_final = h->minmax_partial.ptr + (size_t)512 * 6;
+  hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks), dim3(kBlock), 0, st, pts, n, h->minmax_partial.ptr);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, h->minmax_partial.ptr, mm_blocks, d_final);
+  *d_out6 = d_final;
+  return DGS_OK;
 }
 
 // AABB of the finite points of a device cloud -> host (one stream sync).
 int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]) {
   hipStream_t st = h->stream;
-  const int mm_blocks = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, 512);
-  DGS_HIP_TRY(h, h->minmax_partial.reserve((size_t)mm_blocks * 6 + 8));
+  float* d_final = nullptr;
+  int rc = cloud_minmax_device(h, pts, n, &d_final);
+  if (rc) return rc;
   if (ensure_pinned(h, 4096) != DGS_OK) return DGS_ERR_HIP;
-  float* d_final = h->minmax_partial.ptr + (size_t)mm_blocks * 6;
-  hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks), dim3(kBlock), 0, st, pts, n, h->minmax_partial.ptr);
-  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, h->minmax_partial.ptr, mm_blocks, d_final);
   float* hmm = reinterpret_cast<float*>(h->pinned);
   DGS_HIP_TRY(h, hipMemcpyAsync(hmm, d_final, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
   DGS_HIP_TRY(h, hipStreamSynchronize(st));
@@ -93,76 +113,6 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const float4* __restrict
                                                         float4* __restrict__ out) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) out[i] = pts[order[i]];
-}
-
-// ---- small double linear algebra on one lane ---------------------------------------------------------------
-__device__ inline bool inv3_d(const double* A, double* Ai) {
-  const double c00 = A[4] * A[8] - A[5] * A[7];
-  const double c01 = A[5] * A[6] - A[3] * A[8];
-  const double c02 = A[3] * A[7] - A[4] * A[6];
-  const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
-  const double id = 1.0 / det;
-  Ai[0] = c00 * id;
-  Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id;
-  Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
-  Ai[3] = c01 * id;
-  Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id;
-  Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
-  Ai[6] = c02 * id;
-  Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id;
-  Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
-  return det != 0.0;
-}
-
-// symmetric 3x3 eigen-decomposition (cyclic Jacobi, lower triangle is authoritative), ascending eigenvalues
-__device__ inline void sym_eig3_d(const double* Ain, double* ev, double* V) {
-  double a00 = Ain[0], a11 = Ain[4], a22 = Ain[8], a01 = Ain[3], a02 = Ain[6], a12 = Ain[7];
-  double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int sweep = 0; sweep < 32; sweep++) {
-    const double off = a01 * a01 + a02 * a02 + a12 * a12;
-    const double dia = a00 * a00 + a11 * a11 + a22 * a22;
-    if (off == 0.0 || off <= 1e-34 * dia) break;
-    // rotation (0,1)
-    if (a01 != 0.0) {
-      const double th = (a11 - a00) / (2.0 * a01);
-      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-      const double n00 = a00 - t * a01, n11 = a11 + t * a01;
-      const double n02 = c * a02 - s * a12, n12 = s * a02 + c * a12;
-      a00 = n00; a11 = n11; a01 = 0.0; a02 = n02; a12 = n12;
-      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 0], y = v[k * 3 + 1]; v[k * 3 + 0] = c * x - s * y; v[k * 3 + 1] = s * x + c * y; }
-    }
-    // rotation (0,2)
-    if (a02 != 0.0) {
-      const double th = (a22 - a00) / (2.0 * a02);
-      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-      const double n00 = a00 - t * a02, n22 = a22 + t * a02;
-      const double n01 = c * a01 - s * a12, n12 = s * a01 + c * a12;
-      a00 = n00; a22 = n22; a02 = 0.0; a01 = n01; a12 = n12;
-      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 0], y = v[k * 3 + 2]; v[k * 3 + 0] = c * x - s * y; v[k * 3 + 2] = s * x + c * y; }
-    }
-    // rotation (1,2)
-    if (a12 != 0.0) {
-      const double th = (a22 - a11) / (2.0 * a12);
-      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-      const double n11 = a11 - t * a12, n22 = a22 + t * a12;
-      const double n01 = c * a01 - s * a02, n02 = s * a01 + c * a02;
-      a11 = n11; a22 = n22; a12 = 0.0; a01 = n01; a02 = n02;
-      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 1], y = v[k * 3 + 2]; v[k * 3 + 1] = c * x - s * y; v[k * 3 + 2] = s * x + c * y; }
-    }
-  }
-  double e[3] = {a00, a11, a22};
-  int o0 = 0, o1 = 1, o2 = 2;
-  if (e[o0] > e[o1]) { int t = o0; o0 = o1; o1 = t; }
-  if (e[o1] > e[o2]) { int t = o1; o1 = o2; o2 = t; }
-  if (e[o0] > e[o1]) { int t = o0; o0 = o1; o1 = t; }
-  const int o[3] = {o0, o1, o2};
-  for (int k = 0; k < 3; k++) {
-    ev[k] = e[o[k]];
-    for (int r = 0; r < 3; r++) V[r * 3 + k] = v[r * 3 + o[k]];
-  }
 }
 
 // ---- second pass: one lane per occupied voxel ----------------------------------------------------------------

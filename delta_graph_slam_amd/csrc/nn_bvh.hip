@@ -25,55 +25,21 @@
 #include <cmath>
 
 #include "handle.h"
+#include "nn_group.h"
 
 namespace dgs {
 
-constexpr int kLeaf = 8;    // points per leaf = lanes per query group
-constexpr int kFan = 8;     // children per node
-
-struct BvhView {
-  const float4* sorted;   // Morton order, padded to a multiple of 8; w = original index (bit pattern), -1 for padding
-  const float4* box_lo;   // [node * 8 + child]
-  const float4* box_hi;
-  int n;
-  int depth;              // internal levels D; leaf slots = 8^D
-  int first_leaf;         // heap index of leaf slot 0 = (8^D - 1) / 7
-};
-
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
-  v = (v * 0x00010001u) & 0xFF0000FFu;
-  v = (v * 0x00000101u) & 0x0F00F00Fu;
-  v = (v * 0x00000011u) & 0xC30C30C3u;
-  v = (v * 0x00000005u) & 0x49249249u;
-  return v;
-}
-
-__device__ __forceinline__ uint32_t morton30(float x, float y, float z, const float* org, float scale) {
-  const float fx = fminf(fmaxf((x - org[0]) * scale, 0.f), 1023.f);
-  const float fy = fminf(fmaxf((y - org[1]) * scale, 0.f), 1023.f);
-  const float fz = fminf(fmaxf((z - org[2]) * scale, 0.f), 1023.f);
-  return (expand_bits10((uint32_t)fx) << 2) | (expand_bits10((uint32_t)fy) << 1) | expand_bits10((uint32_t)fz);
-}
-
-__device__ __forceinline__ float sqdist_rn(float ax, float ay, float az, float bx, float by, float bz) {
-  const float dx = sub_rn(ax, bx), dy = sub_rn(ay, by), dz = sub_rn(az, bz);
-  return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-}
-
-__device__ __forceinline__ float aabb_sqdist_rn(const float4 lo, const float4 hi, float x, float y, float z) {
-  const float dx = fmaxf(fmaxf(sub_rn(lo.x, x), sub_rn(x, hi.x)), 0.f);
-  const float dy = fmaxf(fmaxf(sub_rn(lo.y, y), sub_rn(y, hi.y)), 0.f);
-  const float dz = fmaxf(fmaxf(sub_rn(lo.z, z), sub_rn(z, hi.z)), 0.f);
-  return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-}
-
 // ---- build ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict__ pts, int n, float o0, float o1, float o2, float scale,
+__global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict__ pts, int n, const float* __restrict__ mm6,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 p = pts[i];
-  const float org[3] = {o0, o1, o2};
+  // quantisation frame from the device-resident AABB (no host round trip): cubic cells over the largest extent
+  float org[3] = {mm6[0], mm6[1], mm6[2]};
+  float ext = fmaxf(fmaxf(mm6[3] - mm6[0], mm6[4] - mm6[1]), fmaxf(mm6[5] - mm6[2], 1e-6f));
+  if (!(mm6[0] <= mm6[3])) { org[0] = org[1] = org[2] = 0.f; ext = 1.f; }
+  const float scale = 1023.0f / ext;
   // non-finite points sort last and never win a query (their distance compares false)
   keys[i] = (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) ? morton30(p.x, p.y, p.z, org, scale) : 0x3FFFFFFFu;
   vals[i] = (uint32_t)i;
@@ -126,92 +92,6 @@ __global__ __launch_bounds__(kBlock) void bvh_boxes_kernel(const float4* __restr
   box_hi[parent * kFan + slot] = make_float4(mx[0], mx[1], mx[2], 0.f);
 }
 
-// ---- cross-lane helpers inside an 8-lane group (DPP: no LDS traffic) -------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-}
-__device__ __forceinline__ unsigned group8_min_u32(unsigned v) {
-  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror: lane i <-> 7 - i within each 8 lanes
-  return v;
-}
-__device__ __forceinline__ float group8_min_f32(float v) {
-  v = fminf(v, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v))));
-  v = fminf(v, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v))));
-  v = fminf(v, __uint_as_float(dpp_u32<0x141>(__float_as_uint(v))));
-  return v;
-}
-
-// Exact 1-NN of (x, y, z) for the 8-lane group this lane belongs to; x, y, z must be equal across the group.
-// All 8 lanes return the same (best, best_idx).  Lanes of a wave whose group is idle must still call this with
-// `alive` = false (they follow the control flow and touch no memory beyond node 0).
-__device__ void nn_query_group(const BvhView& b, float x, float y, float z, bool alive, float& best, int& best_idx) {
-  const int lane = threadIdx.x & 63;
-  const int sub = lane & 7, gshift = lane & ~7;
-  best = INFINITY;
-  best_idx = 0x7FFFFFFF;
-  int node = 0, level = 0;
-  unsigned long long pend = 0ull;  // one byte of not-yet-visited qualifying children per level
-  bool fresh = true;
-  bool done = !alive;
-  while (__any(!done)) {
-    if (!done) {
-      const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
-      const float d = aabb_sqdist_rn(lo, hi, x, y, z);
-      // empty slots carry inverted boxes (distance +inf): never enter them, even while best is still +inf
-      unsigned mask = (unsigned)((__ballot(d <= best && d < INFINITY) >> gshift) & 0xFFull);
-      if (!fresh) mask &= (unsigned)((pend >> (8 * level)) & 0xFFull);
-      const bool last = (level + 1 == b.depth);
-      if (last) {
-        // children are leaves: scan every qualifying one nearest-first; the boxes stay in registers
-        while (mask) {
-          const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-          const int c = (int)(group8_min_u32(key) & 7u);
-          mask &= ~(1u << c);
-          const int leaf = (node * kFan + 1 + c) - b.first_leaf;
-          const float4 p = b.sorted[leaf * kLeaf + sub];
-          float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
-          if (!(dp == dp)) dp = INFINITY;  // padding / non-finite points
-          const float dmin = group8_min_f32(dp);
-          const unsigned oi = (dp == dmin) ? __float_as_uint(p.w) : 0xFFFFFFFFu;
-          const unsigned imin = group8_min_u32(oi);
-          if (dmin < best || (dmin == best && (int)imin < best_idx)) {
-            best = dmin;
-            best_idx = (int)imin;
-          }
-          mask &= (unsigned)((__ballot(d <= best) >> gshift) & 0xFFull);
-        }
-        // pop
-        fresh = false;
-        if (level == 0) {
-          done = true;
-        } else {
-          level--;
-          node = (node - 1) / kFan;
-        }
-      } else if (mask) {
-        const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-        const int c = (int)(group8_min_u32(key) & 7u);
-        mask &= ~(1u << c);
-        pend = (pend & ~(0xFFull << (8 * level))) | ((unsigned long long)mask << (8 * level));
-        node = node * kFan + 1 + c;
-        level++;
-        fresh = true;
-      } else {
-        fresh = false;
-        if (level == 0) {
-          done = true;
-        } else {
-          level--;
-          node = (node - 1) / kFan;
-        }
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(kBlock) void nn_search_kernel(const BvhView b, const float4* __restrict__ q, int m, int* __restrict__ idx,
                                                            float* __restrict__ sq) {
   const int qi = (blockIdx.x * kBlock + threadIdx.x) >> 3;  // one query per 8 lanes
@@ -219,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void nn_search_kernel(const BvhView b, cons
   const float4 p = alive ? q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
   float best;
   int bi;
-  nn_query_group(b, p.x, p.y, p.z, alive, best, bi);
+  nn_query_group(b, p.x, p.y, p.z, alive, INFINITY, best, bi);
   if (alive && (threadIdx.x & 7) == 0) {
     idx[qi] = bi;
     sq[qi] = best;
@@ -250,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void nn_fitness_kernel(const BvhView b, con
     const float z = affine_row_rn(t20, t21, t22, t23, p.x, p.y, p.z);
     float best;
     int bi;
-    nn_query_group(b, x, y, z, alive, best, bi);
+    nn_query_group(b, x, y, z, alive, INFINITY, best, bi);
     if (alive && sub == 0) {
       if (best <= max_range) {  // PCL compares the SQUARED distance with max_range
         s += (double)best;
@@ -291,11 +171,9 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
   bvh.valid = false;
   bvh.n = n;
   if (n == 0) return DGS_OK;
-  float mm[6];
-  int rc = cloud_minmax(h, pts, n, mm);
+  float* d_mm = nullptr;
+  int rc = cloud_minmax_device(h, pts, n, &d_mm);
   if (rc) return rc;
-  if (!(mm[0] <= mm[3])) { mm[0] = mm[1] = mm[2] = 0.f; mm[3] = mm[4] = mm[5] = 1.f; }
-  const float ext = std::max(std::max(mm[3] - mm[0], mm[4] - mm[1]), std::max(mm[5] - mm[2], 1e-6f));
   const int n_leaves = (n + kLeaf - 1) / kLeaf;
   int depth = 1;
   int64_t slots = kFan;
@@ -315,8 +193,7 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st);
   DGS_HIP_TRY(h, h->cub_temp.reserve(tb + 256));
   const int nb = (n + kBlock - 1) / kBlock;
-  const float scale = 1023.0f / ext;
-  hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, mm[0], mm[1], mm[2], scale, bvh.keys.ptr, bvh.vals.ptr);
+  hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, d_mm, bvh.keys.ptr, bvh.vals.ptr);
   tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st));
   hipLaunchKernelGGL(gather_index_kernel, dim3((n_pad + kBlock - 1) / kBlock), dim3(kBlock), 0, st, pts, bvh.vals_alt.ptr, n, n_pad, bvh.sorted.ptr);
@@ -331,13 +208,11 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
     count /= kFan;
   }
   DGS_HIP_TRY(h, hipGetLastError());
-  bvh.org[0] = mm[0]; bvh.org[1] = mm[1]; bvh.org[2] = mm[2];
-  bvh.scale = scale;
   bvh.valid = true;
   return DGS_OK;
 }
 
-static BvhView make_view(const Bvh& b) {
+BvhView make_bvh_view(const Bvh& b) {
   BvhView v;
   v.sorted = b.sorted.ptr;
   v.box_lo = b.node_lo.ptr;
@@ -356,7 +231,7 @@ static int ensure_target_bvh(dgs_handle* h) {
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq) {
   int rc = ensure_target_bvh(h);
   if (rc) return rc;
-  const BvhView v = make_view(h->target_bvh);
+  const BvhView v = make_bvh_view(h->target_bvh);
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
   hipLaunchKernelGGL(nn_search_kernel, dim3((unsigned)((m * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, queries, (int)m, d_idx, d_sq);
   prof_end(h, DGS_K_NN_SEARCH, slot);
@@ -369,7 +244,7 @@ int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs
   int rc = ensure_target_bvh(h);
   if (rc) return rc;
   hipStream_t st = h->stream;
-  const BvhView v = make_view(h->target_bvh);
+  const BvhView v = make_bvh_view(h->target_bvh);
   const int full = std::max(1, (int)(((int64_t)max_size * 8 + kBlock - 1) / kBlock));  // one query per 8 lanes
   const int bpp = std::max(1, std::min(full, std::max(64, 8192 / std::max(1, n_pairs))));
   DGS_HIP_TRY(h, h->nn_partials.reserve((size_t)n_pairs * bpp * 4 + (size_t)n_pairs * 4));

@@ -1,0 +1,275 @@
+// Cooperative exact nearest-neighbour traversal shared by nn_bvh.hip (fitness / nearestKSearch) and gicp.hip
+// (correspondences, k-NN covariances).  See nn_bvh.hip for the data structure.
+#pragma once
+#include <cfloat>
+#include <cmath>
+
+#include "handle.h"
+
+namespace dgs {
+
+constexpr int kLeaf = 8;    // points per leaf = lanes per query group
+constexpr int kFan = 8;     // children per node
+
+struct BvhView {
+  const float4* sorted;   // Morton order, padded to a multiple of 8; w = original index (bit pattern), -1 for padding
+  const float4* box_lo;   // [node * 8 + child]
+  const float4* box_hi;
+  int n;
+  int depth;              // internal levels D; leaf slots = 8^D
+  int first_leaf;         // heap index of leaf slot 0 = (8^D - 1) / 7
+};
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__device__ __forceinline__ uint32_t morton30(float x, float y, float z, const float* org, float scale) {
+  const float fx = fminf(fmaxf((x - org[0]) * scale, 0.f), 1023.f);
+  const float fy = fminf(fmaxf((y - org[1]) * scale, 0.f), 1023.f);
+  const float fz = fminf(fmaxf((z - org[2]) * scale, 0.f), 1023.f);
+  return (expand_bits10((uint32_t)fx) << 2) | (expand_bits10((uint32_t)fy) << 1) | expand_bits10((uint32_t)fz);
+}
+
+__device__ __forceinline__ float sqdist_rn(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = sub_rn(ax, bx), dy = sub_rn(ay, by), dz = sub_rn(az, bz);
+  return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+}
+
+__device__ __forceinline__ float aabb_sqdist_rn(const float4 lo, const float4 hi, float x, float y, float z) {
+  const float dx = fmaxf(fmaxf(sub_rn(lo.x, x), sub_rn(x, hi.x)), 0.f);
+  const float dy = fmaxf(fmaxf(sub_rn(lo.y, y), sub_rn(y, hi.y)), 0.f);
+  const float dz = fmaxf(fmaxf(sub_rn(lo.z, z), sub_rn(z, hi.z)), 0.f);
+  return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+}
+
+// ---- cross-lane helpers inside an 8-lane group (DPP: no LDS traffic) -------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned group8_min_u32(unsigned v) {
+  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror: lane i <-> 7 - i within each 8 lanes
+  return v;
+}
+__device__ __forceinline__ float group8_min_f32(float v) {
+  v = fminf(v, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(v))));
+  v = fminf(v, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(v))));
+  v = fminf(v, __uint_as_float(dpp_u32<0x141>(__float_as_uint(v))));
+  return v;
+}
+
+// Exact 1-NN of (x, y, z) for the 8-lane group this lane belongs to; x, y, z must be equal across the group.
+// All 8 lanes return the same (best, best_idx).  Lanes of a wave whose group is idle must still call this with
+// `alive` = false (they follow the control flow and touch no memory beyond node 0).
+__device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float y, float z, bool alive, float bound, float& best, int& best_idx) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7, gshift = lane & ~7;
+  best = bound;  // only points with squared distance <= bound are reported (INFINITY: unbounded)
+  best_idx = 0x7FFFFFFF;
+  int node = 0, level = 0;
+  unsigned long long pend = 0ull;  // one byte of not-yet-visited qualifying children per level
+  bool fresh = true;
+  bool done = !alive;
+  while (__any(!done)) {
+    if (!done) {
+      const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
+      const float d = aabb_sqdist_rn(lo, hi, x, y, z);
+      // empty slots carry inverted boxes (distance +inf): never enter them, even while best is still +inf
+      unsigned mask = (unsigned)((__ballot(d <= best && d < INFINITY) >> gshift) & 0xFFull);
+      if (!fresh) mask &= (unsigned)((pend >> (8 * level)) & 0xFFull);
+      const bool last = (level + 1 == b.depth);
+      if (last) {
+        // children are leaves: scan every qualifying one nearest-first; the boxes stay in registers
+        while (mask) {
+          const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+          const int c = (int)(group8_min_u32(key) & 7u);
+          mask &= ~(1u << c);
+          const int leaf = (node * kFan + 1 + c) - b.first_leaf;
+          const float4 p = b.sorted[leaf * kLeaf + sub];
+          float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
+          if (!(dp == dp)) dp = INFINITY;  // padding / non-finite points
+          const float dmin = group8_min_f32(dp);
+          const unsigned oi = (dp == dmin) ? __float_as_uint(p.w) : 0xFFFFFFFFu;
+          const unsigned imin = group8_min_u32(oi);
+          if (dmin < best || (dmin == best && (int)imin < best_idx)) {
+            best = dmin;
+            best_idx = (int)imin;
+          }
+          mask &= (unsigned)((__ballot(d <= best) >> gshift) & 0xFFull);
+        }
+        // pop
+        fresh = false;
+        if (level == 0) {
+          done = true;
+        } else {
+          level--;
+          node = (node - 1) / kFan;
+        }
+      } else if (mask) {
+        const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+        const int c = (int)(group8_min_u32(key) & 7u);
+        mask &= ~(1u << c);
+        pend = (pend & ~(0xFFull << (8 * level))) | ((unsigned long long)mask << (8 * level));
+        node = node * kFan + 1 + c;
+        level++;
+        fresh = true;
+      } else {
+        fresh = false;
+        if (level == 0) {
+          done = true;
+        } else {
+          level--;
+          node = (node - 1) / kFan;
+        }
+      }
+    }
+  }
+}
+
+
+
+// ---- exact k-NN for the 8-lane group (k <= 32): the k best (distance, index) pairs live in registers, 4 slots per lane,
+// sorted ascending over slot = r * 8 + sub.  Candidates are compared lexicographically on (distance, index), so the set
+// is deterministic; pruning tests the box distance against the current k-th best.
+constexpr int kKnnSlots = 4;
+constexpr int kKnnMax = kKnnSlots * 8;
+struct KnnList {
+  float d[kKnnSlots];
+  int id[kKnnSlots];
+};
+
+__device__ __forceinline__ double group8_sum_f64(double v) {
+  {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+    v += __hiloint2double(hi, lo);
+  }
+  {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, false);
+    v += __hiloint2double(hi, lo);
+  }
+  {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x141, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x141, 0xf, 0xf, false);
+    v += __hiloint2double(hi, lo);
+  }
+  return v;
+}
+
+__device__ __forceinline__ void knn_threshold(const KnnList& L, int k, int gshift, float& td, int& ti) {
+  const int rk = (k - 1) >> 3, lk = gshift + ((k - 1) & 7);
+  const float vd = (rk == 0) ? L.d[0] : (rk == 1) ? L.d[1] : (rk == 2) ? L.d[2] : L.d[3];
+  const int vi = (rk == 0) ? L.id[0] : (rk == 1) ? L.id[1] : (rk == 2) ? L.id[2] : L.id[3];
+  td = __shfl(vd, lk, 64);
+  ti = __shfl(vi, lk, 64);
+}
+
+__device__ __forceinline__ void knn_insert(KnnList& L, float cd, int ci, int sub, int gshift) {
+  int p = 0;
+#pragma unroll
+  for (int r = 0; r < kKnnSlots; r++) {
+    const bool lt = (L.d[r] < cd) || (L.d[r] == cd && L.id[r] < ci);
+    p += __popc((unsigned)((__ballot(lt) >> gshift) & 0xFFull));
+  }
+  float nd[kKnnSlots];
+  int ni[kKnnSlots];
+#pragma unroll
+  for (int r = 0; r < kKnnSlots; r++) {
+    // previous slot: lane sub-1 of the same row, or lane 7 of row r-1
+    float pd = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(L.d[r]), 0x111, 0xf, 0xf, false));  // row_shr:1
+    int pi = __builtin_amdgcn_update_dpp(0, L.id[r], 0x111, 0xf, 0xf, false);
+    if (r > 0) {
+      const float wd = __shfl(L.d[r - 1], gshift + 7, 64);
+      const int wi = __shfl(L.id[r - 1], gshift + 7, 64);
+      if (sub == 0) { pd = wd; pi = wi; }
+    }
+    const int slot = r * 8 + sub;
+    nd[r] = (slot > p) ? pd : (slot == p ? cd : L.d[r]);
+    ni[r] = (slot > p) ? pi : (slot == p ? ci : L.id[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < kKnnSlots; r++) { L.d[r] = nd[r]; L.id[r] = ni[r]; }
+}
+
+// All 8 lanes of the group end with the same distributed list.  `alive` = false lanes follow the control flow only.
+__device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7, gshift = lane & ~7;
+#pragma unroll
+  for (int r = 0; r < kKnnSlots; r++) { L.d[r] = INFINITY; L.id[r] = 0x7FFFFFFF; }
+  float td = INFINITY;
+  int ti = 0x7FFFFFFF;
+  int node = 0, level = 0;
+  unsigned long long pend = 0ull;
+  bool fresh = true;
+  bool done = !alive;
+  while (__any(!done)) {
+    if (!done) {
+      const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
+      const float d = aabb_sqdist_rn(lo, hi, x, y, z);
+      unsigned mask = (unsigned)((__ballot(d <= td && d < INFINITY) >> gshift) & 0xFFull);
+      if (!fresh) mask &= (unsigned)((pend >> (8 * level)) & 0xFFull);
+      const bool last = (level + 1 == b.depth);
+      if (last) {
+        while (mask) {
+          const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+          const int c = (int)(group8_min_u32(key) & 7u);
+          mask &= ~(1u << c);
+          const int leaf = (node * kFan + 1 + c) - b.first_leaf;
+          const float4 p = b.sorted[leaf * kLeaf + sub];
+          float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
+          if (!(dp == dp)) dp = INFINITY;
+          const int oi = (int)__float_as_uint(p.w);
+          unsigned pm = (unsigned)((__ballot((dp < td) || (dp == td && oi < ti)) >> gshift) & 0xFFull);
+          while (pm) {
+            const int c2 = __ffs((int)pm) - 1;
+            pm &= pm - 1u;
+            const float cd = __shfl(dp, gshift + c2, 64);
+            const int ci = __shfl(oi, gshift + c2, 64);
+            if ((cd < td) || (cd == td && ci < ti)) {
+              knn_insert(L, cd, ci, sub, gshift);
+              knn_threshold(L, k, gshift, td, ti);
+            }
+          }
+          mask &= (unsigned)((__ballot(d <= td) >> gshift) & 0xFFull);
+        }
+        fresh = false;
+        if (level == 0) {
+          done = true;
+        } else {
+          level--;
+          node = (node - 1) / kFan;
+        }
+      } else if (mask) {
+        const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+        const int c = (int)(group8_min_u32(key) & 7u);
+        mask &= ~(1u << c);
+        pend = (pend & ~(0xFFull << (8 * level))) | ((unsigned long long)mask << (8 * level));
+        node = node * kFan + 1 + c;
+        level++;
+        fresh = true;
+      } else {
+        fresh = false;
+        if (level == 0) {
+          done = true;
+        } else {
+          level--;
+          node = (node - 1) / kFan;
+        }
+      }
+    }
+  }
+}
+
+// host: device view of a built index (nn_bvh.hip)
+BvhView make_bvh_view(const Bvh& b);
+
+}  // namespace dgs

@@ -227,6 +227,21 @@ class Registration:
                                                    C.byref(s), g.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
         return s.value, g, H
 
+    def gicp_covariances(self, which: str = "source", n: int | None = None):
+        n = self._n_source if (which == "source" and n is None) else n
+        out = np.zeros((n, 3, 3))
+        self._check(self._lib.dgs_gicp_get_covariances(self._h, 0 if which == "source" else 1, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def gicp_linearize(self, T, error_only: bool = False):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        e = C.c_double(0)
+        H = np.zeros((6, 6))
+        b = np.zeros(6)
+        self._check(self._lib.dgs_gicp_linearize(self._h, T.ctypes.data_as(C.c_void_p), 1 if error_only else 0, C.byref(e),
+                                                  H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        return (e.value,) if error_only else (e.value, H, b)
+
     def ndt_trajectory(self, pair: int = 0):
         buf = np.zeros((72, 6))
         n = C.c_int32(0)

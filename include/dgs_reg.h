@@ -185,6 +185,14 @@ int dgs_ndt_get_trajectory(dgs_handle* h, int32_t pair, double* poses6, int32_t*
 int dgs_ndt_get_voxels(dgs_handle* h, int64_t* n, int64_t* keys, int32_t* counts, int32_t* valid, double* mean3,
                        double* icov9);
 
+/* GICP regularised k-NN covariances (FastGICP::calculate_covariances): which = 0 source, 1 target;
+ * cov9 receives 9 doubles (row-major 3x3) per point. */
+int dgs_gicp_get_covariances(dgs_handle* h, int32_t which, double* cov9);
+/* GICP FastGICP::linearize (error_only = 0: new correspondences at the pose; returns sum of errors, H 6x6, b 6) or
+ * FastGICP::compute_error (error_only = 1: correspondences / Mahalanobis matrices of the last linearisation).
+ * The pose is a row-major double 4x4 (Eigen::Isometry3d). */
+int dgs_gicp_linearize(dgs_handle* h, const double* T16_rowmajor, int32_t error_only, double* error, double* hess36, double* b6);
+
 #ifdef __cplusplus
 }
 #endif

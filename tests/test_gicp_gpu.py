@@ -1,0 +1,112 @@
+"""-m gpu parity tests for the FAST_GICP hot path: HIP (through the C ABI) vs the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+
+from delta_graph_slam_amd import synth
+from tests.helpers import TOL_ROT, TOL_TRANS, pose_error
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(oracle_lib, tgt, src, reg="PLANE", **kw):
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd.registration import Registration
+    o = oracle_lib.GicpOracle(regularization=reg, max_correspondence_distance=kw.get("dmax", 2.0),
+                              transformation_epsilon=kw.get("eps", 0.01), optimizer=kw.get("optimizer", 1),
+                              k_correspondences=kw.get("k", 20))
+    o.set_target(tgt)
+    o.set_source(src)
+    r = Registration("FAST_GICP", gicp_max_correspondence_distance=kw.get("dmax", 2.0), transformation_epsilon=kw.get("eps", 0.01),
+                     gicp_regularization=L.GICP_REG[reg], gicp_optimizer=kw.get("optimizer", 1),
+                     gicp_correspondence_randomness=kw.get("k", 20))
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    return o, r
+
+
+@pytest.mark.parametrize("reg", ["PLANE", "FROBENIUS", "MIN_EIG", "NORMALIZED_MIN_EIG", "NONE"])
+def test_covariances_match_oracle(oracle_lib, reg):
+    tgt, src, _ = synth.planar_pair(n=4096)
+    o, r = _pair(oracle_lib, tgt, src, reg=reg)
+    for which, n in (("source", src.shape[0]), ("target", tgt.shape[0])):
+        co = o.covariances(which)
+        cg = r.gicp_covariances(which, n)
+        # same neighbour sets (exact k-NN), double arithmetic: agreement to rounding of the eigen-decomposition
+        err = np.abs(co - cg).max(axis=(1, 2)) / np.abs(co).max(axis=(1, 2))
+        assert np.quantile(err, 0.999) < 1e-9, (which, err.max())
+        assert (err > 1e-6).mean() < 1e-3        # a tie at the k-th neighbour may swap one member
+
+
+def test_covariances_small_k_and_tiny_cloud(oracle_lib):
+    rng = np.random.default_rng(0)
+    tiny = np.ones((11, 4), np.float32)
+    tiny[:, :3] = rng.normal(size=(11, 3))
+    o, r = _pair(oracle_lib, tiny, tiny, k=20)      # fewer points than k: missing neighbours are zero columns upstream
+    assert np.allclose(o.covariances("source"), r.gicp_covariances("source", 11), rtol=1e-9, atol=1e-12)
+    tgt, src, _ = synth.planar_pair(n=2048)
+    o, r = _pair(oracle_lib, tgt, src, k=5)
+    assert np.allclose(o.covariances("source"), r.gicp_covariances("source", 2048), rtol=1e-8, atol=1e-12)
+
+
+def test_linearize_and_error_match_oracle(oracle_lib):
+    tgt, src, _ = synth.planar_pair(n=8192)
+    o, r = _pair(oracle_lib, tgt, src)
+    for t, rot in (((0, 0, 0), (0, 0, 0)), ((0.25, -0.08, 0.04), (0.01, -0.015, 0.04))):
+        T = synth.make_transform(t, rot)
+        eo, Ho, bo = o.linearize(T)
+        eg, Hg, bg = r.gicp_linearize(T)
+        assert abs(eo - eg) <= 1e-9 * abs(eo)
+        assert np.abs(Ho - Hg).max() <= 1e-9 * np.abs(Ho).max()
+        assert np.abs(bo - bg).max() <= 1e-9 * np.abs(bo).max()
+        T2 = synth.make_transform((t[0] + 0.01, t[1], t[2] - 0.005), (rot[0], rot[1] + 0.002, rot[2]))
+        assert abs(o.compute_error(T2) - r.gicp_linearize(T2, error_only=True)[0]) <= 1e-9 * abs(eo)
+
+
+@pytest.mark.parametrize("optimizer", [1, 0])
+def test_align_cfg1_matches_oracle(oracle_lib, optimizer):
+    tgt, src, Tgt = synth.planar_pair()
+    o, r = _pair(oracle_lib, tgt, src, optimizer=optimizer)
+    ro = o.align()
+    r.align()
+    assert r.hasConverged() == ro["converged"]
+    assert r.last_result.iterations == ro["iterations"]
+    assert r.last_result.evaluations == ro["evaluations"]
+    dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+    assert dt <= TOL_TRANS and dr <= TOL_ROT, (dt, dr)
+    dt, dr = pose_error(r.getFinalTransformation(), Tgt)
+    assert dt < 0.01 and dr < 1e-3
+    fit = r.getFitnessScore()
+    fo, _, _ = oracle_lib.fitness_score(tgt, src, r.getFinalTransformation())
+    assert abs(fit - fo) <= 1e-12 * fo
+
+
+def test_align_with_guess_vlp16_frames(oracle_lib):
+    clouds, poses = synth.vlp16_stream(n_frames=3)
+    tgt, src = clouds[0], clouds[2]
+    Tgt = np.linalg.inv(poses[0]) @ poses[2]
+    guess = np.eye(4, dtype=np.float32)
+    guess[:3, 3] = Tgt[:3, 3] * 0.8
+    o, r = _pair(oracle_lib, tgt, src, dmax=2.0, eps=0.1)      # launch-file values (delta_graph_slam.launch:60-69)
+    ro = o.align(guess)
+    r.align(guess)
+    assert r.hasConverged() == ro["converged"] and r.last_result.iterations == ro["iterations"]
+    dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+    assert dt <= TOL_TRANS and dr <= TOL_ROT, (dt, dr)
+    dt, dr = pose_error(r.getFinalTransformation(), Tgt)
+    assert dt < 0.3 and dr < 2e-2      # sanity only: a street canyon seen by 16 beams constrains x weakly at eps 0.1
+
+
+def test_batch_is_sequential_singles(oracle_lib):
+    tgt, src, _ = synth.planar_pair(n=4096)
+    o, r = _pair(oracle_lib, tgt, src)
+    sources = [src[:3000].copy(), src.copy(), np.zeros((0, 4), np.float32)]
+    guesses = [np.eye(4, dtype=np.float32)] * 3
+    res = r.align_batch(sources, guesses, compute_fitness=True)
+    assert res[2]["status"] == 4 and not res[2]["converged"]
+    for k in range(2):
+        o.set_source(sources[k])
+        ro = o.align()
+        dt, dr = pose_error(res[k]["T"], ro["T"])
+        assert dt <= TOL_TRANS and dr <= TOL_ROT
+        fo, _, _ = oracle_lib.fitness_score(tgt, sources[k], res[k]["T"])
+        assert abs(res[k]["fitness"] - fo) <= 1e-12 * fo
