@@ -1,0 +1,86 @@
+"""CPU tests of the host-side mirror: 2-D/3-D guess flattening, candidate filtering, arg-min tie-breaking, generators."""
+import hashlib
+
+import numpy as np
+
+from delta_graph_slam_amd import synth
+from delta_graph_slam_amd.loop_detector import RECORD_WIDTH, KeyFrame, LoopDetector
+from delta_graph_slam_amd.transforms import euler_angles_012, normalize_euler_angs, transform2Dto3D, transform3Dto2D
+
+
+def _se2(x, y, yaw):
+    c, s = np.cos(yaw), np.sin(yaw)
+    return np.array([[c, -s, x], [s, c, y], [0, 0, 1.0]])
+
+
+def test_transform2d3d_roundtrip():
+    """ros_utils.cpp:105-144"""
+    for x, y, yaw in [(1.0, -2.0, 0.3), (0.0, 0.0, -2.5), (5.0, 1.0, 3.1)]:
+        T3 = transform2Dto3D(_se2(x, y, yaw))
+        assert T3.dtype == np.float32 and T3[2, 3] == 0 and T3[2, 2] == 1
+        assert np.allclose(T3[:2, 3], [x, y], atol=1e-6)
+        T2 = transform3Dto2D(T3)
+        assert np.allclose(T2, _se2(x, y, yaw), atol=2e-6)
+
+
+def test_transform3dto2d_ignores_roll_pitch_like_the_reference():
+    T = synth.make_transform((1, 2, 3), (0.02, -0.03, 0.7)).astype(np.float32)
+    T2 = transform3Dto2D(T)
+    e = normalize_euler_angs(euler_angles_012(T[:3, :3]))
+    assert abs(e[2] - 0.7) < 1e-5
+    assert np.allclose(T2[:2, 2], [1, 2]) and abs(np.arctan2(T2[1, 0], T2[0, 0]) - e[2]) < 1e-6
+
+
+def test_euler_angles_match_eigen_convention():
+    # Eigen's eulerAngles(0,1,2) returns the first angle in [0, pi]; the triple must still reproduce the rotation
+    for r in [(0.01, -0.02, 0.05), (-0.01, 0.02, -0.05), (-2.0, 0.4, 1.0), (3.0, -1.2, -2.0)]:
+        R = synth.euler_to_matrix(*r)
+        e = euler_angles_012(R.astype(np.float32))
+        assert 0.0 <= e[0] <= np.pi + 1e-6
+        assert np.allclose(synth.euler_to_matrix(*e.astype(np.float64)), R, atol=2e-6)
+
+
+def test_find_candidates_follows_the_reference_filters():
+    """loop_detector.hpp:83-111"""
+    det = LoopDetector({"distance_thresh": 5.0, "accum_distance_thresh": 8.0, "min_edge_interval": 5.0}, registration=object())
+    kfs = [KeyFrame(None, _se2(0, 0, 0), 0.0), KeyFrame(None, _se2(3, 0, 0), 3.0), KeyFrame(None, _se2(30, 0, 0), 30.0),
+           KeyFrame(None, _se2(1, 1, 0), 45.0)]
+    new = KeyFrame(None, _se2(1, 0, 0), 50.0)
+    c = det.find_candidates(kfs, new)
+    assert [k.accum_distance for k in c] == [0.0, 3.0]          # #2 too far in space, #3 too close in travelled distance
+    det.last_edge_accum_distance = 47.0
+    assert det.find_candidates(kfs, new) == []                   # too close to the last loop edge
+
+
+def test_select_best_tie_goes_to_the_later_candidate():
+    """loop_detector.hpp:149: a candidate is skipped only if score > best, so an exact tie replaces the earlier one."""
+    rec = np.full((5, RECORD_WIDTH), -1.0)
+    rec[:, 0] = np.arange(5)
+    rec[:, 1] = [1, 1, 0, 1, 1]
+    rec[:, 2] = [0.30, 0.20, 0.01, 0.20, 0.25]
+    best, score = LoopDetector.select_best(rec)
+    assert best == 3 and score == 0.20                           # #2 is better but did not converge; #1 and #3 tie -> #3
+    rec[:, 1] = 0
+    assert LoopDetector.select_best(rec)[0] == -1
+
+
+def test_guess_is_relative_pose_flattened():
+    new = KeyFrame(None, _se2(10, 5, 0.5), 0)
+    cand = KeyFrame(None, _se2(11, 5.5, 0.7), 0)
+    G = LoopDetector.guess_for(new, cand)
+    rel = np.linalg.inv(_se2(10, 5, 0.5)) @ _se2(11, 5.5, 0.7)
+    assert np.allclose(G[:2, 3], rel[:2, 2], atol=1e-6) and abs(np.arctan2(G[1, 0], G[0, 0]) - 0.2) < 1e-6
+    assert G[2, 3] == 0 and G[2, 2] == 1
+
+
+def test_generators_are_deterministic_and_shaped():
+    a1, b1, T1 = synth.planar_pair(n=4096)
+    a2, b2, T2 = synth.planar_pair(n=4096)
+    assert hashlib.sha1(a1.tobytes()).hexdigest() == hashlib.sha1(a2.tobytes()).hexdigest()
+    assert a1.shape == (4096, 4) and a1.dtype == np.float32 and np.all(a1[:, 3] == 1)
+    s, Tw = synth.hdl64_scan((0.0, 0.0, 0.0), seed=10, n_points=65536)
+    assert s.shape == (65536, 4) and np.isfinite(s).all()
+    r = np.linalg.norm(s[:, :3], axis=1)
+    assert r.min() > 0.05 and r.max() <= 100.5                   # distance filter of delta_graph_slam.launch:31-33
+    clouds, poses = synth.vlp16_stream(n_frames=2)
+    assert all(20000 < c.shape[0] <= 30000 for c in clouds)      # ragged: sky rays miss
