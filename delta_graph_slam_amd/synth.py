@@ -87,7 +87,8 @@ _GAP_WIDTH = 3.0
 
 
 def _street_scene(seed: int = 7):
-    """12 car-sized boxes + 20 pole cylinders, fixed by seed (scene is shared by all scans)."""
+    """12 car-sized boxes, 20 pole cylinders and 48 facade buttresses (bay fronts of random width / depth that break
+    the along-street symmetry of the two planar facades), fixed by seed: the scene is shared by all scans."""
     rng = np.random.default_rng(seed)
     boxes = []
     for k in range(12):
@@ -96,6 +97,12 @@ def _street_scene(seed: int = 7):
         cy = side * rng.uniform(3.5, 6.0)
         lx, ly, lz = rng.uniform(3.8, 4.8), rng.uniform(1.6, 1.9), rng.uniform(1.4, 1.8)
         boxes.append((cx - lx / 2, cy - ly / 2, 0.0, cx + lx / 2, cy + ly / 2, lz))
+    for k in range(48):
+        side = 1.0 if k % 2 == 0 else -1.0
+        cx = -118.0 + 5.0 * k + rng.uniform(-2.0, 2.0)
+        w, d, hgt = rng.uniform(0.8, 3.0), rng.uniform(0.3, 1.2), rng.uniform(3.0, _FACADE_H)
+        y0, y1 = (_FACADE_Y - d, _FACADE_Y) if side > 0 else (-_FACADE_Y, -_FACADE_Y + d)
+        boxes.append((cx - w / 2, y0, 0.0, cx + w / 2, y1, hgt))
     poles = []
     for k in range(20):
         px = -76.0 + 8.0 * k + rng.uniform(-1, 1)
@@ -104,12 +111,25 @@ def _street_scene(seed: int = 7):
     return np.array(boxes), np.array(poles)
 
 
-def _raycast(origin: np.ndarray, dirs: np.ndarray, boxes: np.ndarray, poles: np.ndarray) -> np.ndarray:
-    """Range to nearest surface along unit dirs [M,3] from origin; inf on miss. float64."""
-    M = dirs.shape[0]
-    t_best = np.full(M, np.inf)
+def _az_span(origin, yaw, xs, ys, n_az):
+    """Inclusive azimuth-index span [i0, i0 + cnt) (modulo n_az) of the rays that can see points (xs, ys)."""
+    ang = np.arctan2(ys - origin[1], xs - origin[0]) - yaw
+    ref = ang[0]
+    rel = np.mod(ang - ref + np.pi, 2 * np.pi) - np.pi          # unwrap around the first corner
+    lo, hi = ref + rel.min(), ref + rel.max()
+    step = 2 * np.pi / n_az
+    i0 = int(np.floor(lo / step)) - 1
+    cnt = int(np.ceil((hi - lo) / step)) + 3
+    return i0, min(cnt, n_az)
+
+
+def _raycast(origin: np.ndarray, yaw: float, dirs: np.ndarray, boxes: np.ndarray, poles: np.ndarray) -> np.ndarray:
+    """Range to the nearest surface along unit dirs [beams, n_az, 3] (world frame) from origin; inf on miss. float64.
+    Boxes and poles are only tested against the azimuth sector they subtend."""
+    nb, na, _ = dirs.shape
+    t_best = np.full((nb, na), np.inf)
     ox, oy, oz = origin
-    dx, dy, dz = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    dx, dy, dz = dirs[..., 0], dirs[..., 1], dirs[..., 2]
     with np.errstate(divide="ignore", invalid="ignore"):
         # ground z = 0
         t = np.where(dz < 0, -oz / dz, np.inf)
@@ -121,28 +141,37 @@ def _raycast(origin: np.ndarray, dirs: np.ndarray, boxes: np.ndarray, poles: np.
             hz = oz + t * dz
             ok = (t > 0) & (hz >= 0) & (hz <= _FACADE_H) & (np.mod(hx, _GAP_PERIOD) >= _GAP_WIDTH)
             t_best = np.minimum(t_best, np.where(ok, t, np.inf))
-        # boxes (slab test)
-        inv = 1.0 / dirs
+        # boxes (slab test) on their azimuth sector
         for b in boxes:
+            inside = b[0] <= ox <= b[3] and b[1] <= oy <= b[4]
+            if inside:
+                cols = np.arange(na)
+            else:
+                i0, cnt = _az_span(origin, yaw, np.array([b[0], b[0], b[3], b[3]]), np.array([b[1], b[4], b[1], b[4]]), na)
+                cols = np.mod(np.arange(i0, i0 + cnt), na)
+            d = dirs[:, cols, :]
+            inv = 1.0 / d
             t0 = (b[:3] - origin) * inv
             t1 = (b[3:] - origin) * inv
-            tmin = np.max(np.minimum(t0, t1), axis=1)
-            tmax = np.min(np.maximum(t0, t1), axis=1)
+            tmin = np.minimum(t0, t1).max(axis=2)
+            tmax = np.maximum(t0, t1).min(axis=2)
             ok = (tmax >= tmin) & (tmin > 0)
-            t_best = np.minimum(t_best, np.where(ok, tmin, np.inf))
-        # vertical cylinders
-        a = dx * dx + dy * dy
+            t_best[:, cols] = np.minimum(t_best[:, cols], np.where(ok, tmin, np.inf))
+        # vertical cylinders on their azimuth sector
         for (px, py, r, h) in poles:
+            i0, cnt = _az_span(origin, yaw, np.array([px - r, px + r, px - r, px + r]), np.array([py - r, py - r, py + r, py + r]), na)
+            cols = np.mod(np.arange(i0, i0 + cnt), na)
+            ddx, ddy, ddz = dx[:, cols], dy[:, cols], dz[:, cols]
+            a = ddx * ddx + ddy * ddy
             fx, fy = ox - px, oy - py
-            bq = 2 * (fx * dx + fy * dy)
+            bq = 2 * (fx * ddx + fy * ddy)
             cq = fx * fx + fy * fy - r * r
             disc = bq * bq - 4 * a * cq
-            sq = np.sqrt(np.maximum(disc, 0.0))
-            t = (-bq - sq) / (2 * a)
-            hz = oz + t * dz
+            t = (-bq - np.sqrt(np.maximum(disc, 0.0))) / (2 * a)
+            hz = oz + t * ddz
             ok = (disc >= 0) & (t > 0) & (hz >= 0) & (hz <= h)
-            t_best = np.minimum(t_best, np.where(ok, t, np.inf))
-    return t_best
+            t_best[:, cols] = np.minimum(t_best[:, cols], np.where(ok, t, np.inf))
+    return t_best.reshape(-1)
 
 
 def voxel_centroid_downsample(xyz: np.ndarray, leaf: float) -> np.ndarray:
@@ -176,7 +205,7 @@ def street_scan(pose_xy_yaw, beams: int, elev_deg, azimuths: int, seed: int, ran
     d_s = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
     T = make_transform((x, y, sensor_z), (0.0, 0.0, yaw))
     d_w = d_s @ T[:3, :3].T
-    t = _raycast(T[:3, 3], d_w, boxes, poles)
+    t = _raycast(T[:3, 3], yaw, d_w.reshape(beams, azimuths, 3), boxes, poles)
     rng = np.random.default_rng(seed)
     t = t + rng.normal(0.0, range_sigma, t.shape)
     ok = np.isfinite(t) & (t >= rmin) & (t <= rmax)

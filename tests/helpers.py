@@ -34,3 +34,28 @@ def f32_transform(T, xyz):
     for r in range(3):
         out[:, r] = ((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3]
     return out
+
+
+def _ulp_shift(G, k):
+    """Move the guess translation by k float32 ulps (x up, y down): a perturbation below the input's own resolution."""
+    Gp = np.asarray(G, np.float32).copy()
+    for _ in range(abs(k)):
+        Gp[0, 3] = np.nextafter(Gp[0, 3], np.float32(np.inf if k > 0 else -np.inf))
+        Gp[1, 3] = np.nextafter(Gp[1, 3], np.float32(-np.inf if k > 0 else np.inf))
+    return Gp
+
+
+def ndt_oracle_band(orc, tgt, src, guess=None, **kw):
+    """The reference algorithm's own reproducibility on one pair: the largest deviation of the oracle's answer under
+    perturbations that carry no information -- the same source compiled with FMA contraction, and the float32 initial
+    guess moved by +-1 and +-2 ulps.  Returns (result of the unperturbed oracle, band_translation, band_rotation)."""
+    G = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, np.float32)
+    runs = []
+    for perturbed, k in ((False, 0), (True, 0), (False, 1), (False, -1), (False, 2), (False, -2)):
+        o = orc.NdtOracle(perturbed=perturbed, **kw)
+        o.set_target(tgt)
+        o.set_source(src)
+        runs.append(o.align(_ulp_shift(G, k)))
+    bt = max(pose_error(r["T"], runs[0]["T"])[0] for r in runs[1:])
+    br = max(pose_error(r["T"], runs[0]["T"])[1] for r in runs[1:])
+    return runs[0], bt, br

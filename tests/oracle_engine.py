@@ -31,3 +31,36 @@ class OracleEngine:
             out.append(dict(T=r["T"], converged=r["converged"], iterations=r["iterations"], evaluations=r["evaluations"], status=0,
                             score=r["score"], fitness=fit))
         return out
+
+
+class OracleRegistration:
+    """TEST-ONLY pcl::Registration-shaped object over the CPU oracle (same method names as
+    delta_graph_slam_amd.registration.Registration), used to check the odometry driver's call sequence."""
+
+    def __init__(self, method="FAST_GICP", **kw):
+        self.o = orc.GicpOracle(**kw) if "GICP" in method else orc.NdtOracle(**kw)
+        self.target = self.source = None
+        self._r = None
+
+    def setInputTarget(self, cloud):
+        self.target = np.asarray(cloud, np.float32)
+        self.o.set_target(self.target)
+
+    def setInputSource(self, cloud):
+        self.source = np.asarray(cloud, np.float32)
+        self.o.set_source(self.source)
+
+    def align(self, guess=None, want_aligned=False):
+        self._r = self.o.align(guess)
+
+    def hasConverged(self):
+        return self._r["converged"]
+
+    def getFinalTransformation(self):
+        return self._r["T"].copy()
+
+    def getFitnessScore(self, max_range=1.7976931348623157e308):
+        return orc.fitness_score(self.target, self.source, self._r["T"], max_range)[0]
+
+    def getInlierFraction(self, max_sq=0.25):
+        return orc.fitness_score(self.target, self.source, self._r["T"], 1.7976931348623157e308, max_sq)[2] / self.source.shape[0]

