@@ -103,7 +103,8 @@ def test_odometry_driver_sequence_on_cpu_engine():
     gt = [np.linalg.inv(poses[0]) @ p for p in poses]
     for o, g in zip(out[1:], gt[1:]):
         assert o.shape == (4, 4) and o.dtype == np.float32
-        assert abs(o[1, 3] - g[1, 3]) < 0.02 and abs(o[0, 3] - g[0, 3]) < 0.25    # a street canyon constrains x weakly
+        assert abs(o[1, 3] - g[1, 3]) < 0.02 and abs(o[0, 3] - g[0, 3]) < 0.06
     # the keyframe is replaced as soon as |trans| exceeds keyframe_delta_trans (:249-260) and prev_trans restarts from I
-    assert odo.n_keyframes == 2
-    assert np.linalg.norm(odo.prev_trans[:3, 3]) < 0.5
+    # 0.3 m per frame against keyframe_delta_trans 0.5: the keyframe is replaced after frames 2 and 4
+    assert odo.n_keyframes == 3
+    assert np.array_equal(odo.prev_trans, np.eye(4, dtype=np.float32))            # reset at the last switch (:259)
