@@ -168,7 +168,14 @@ def main():
             from oracle import oracle as orc
             ncpu = orc.max_threads()
 
-            def cpu_run(threads, budget, perturbed=False, limit=P):
+            def ulp_shift(G, k):   # move the float32 guess by k ulps: a perturbation below the input's own resolution
+                Gp = np.asarray(G, np.float32).copy()
+                for _ in range(abs(k)):
+                    Gp[0, 3] = np.nextafter(Gp[0, 3], np.float32(np.inf if k > 0 else -np.inf))
+                    Gp[1, 3] = np.nextafter(Gp[1, 3], np.float32(-np.inf if k > 0 else np.inf))
+                return Gp
+
+            def cpu_run(threads, budget, perturbed=False, limit=P, ulps=0):
                 o = orc.NdtOracle(resolution=args.resolution, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
                                   num_threads=threads, perturbed=perturbed)
                 tc0 = time.perf_counter()
@@ -177,28 +184,34 @@ def main():
                 while len(Ts) < limit:
                     c = len(Ts)
                     o.set_source(sources[c])
-                    Ts.append(o.align(guesses[c])["T"])
+                    Ts.append(o.align(ulp_shift(guesses[c], ulps))["T"])
                     if t_first is None:
                         t_first = time.perf_counter() - tc0
                     if len(Ts) >= 2 and (time.perf_counter() - tc0) + t_first > budget:
                         break
                 return Ts, time.perf_counter() - tc0
 
-            # all host cores (the reference's reg_num_threads=0 default), and a 16-thread run in case the box over-subscribes
-            T_all, t_all = cpu_run(ncpu, args.cpu_seconds)
-            T_16, t_16 = cpu_run(min(16, ncpu), args.cpu_seconds / 3, limit=len(T_all))
-            rate_all, rate_16 = len(T_all) / t_all, len(T_16) / t_16
-            best_rate, best_cores, best_n, best_t = (rate_all, ncpu, len(T_all), t_all) if rate_all >= rate_16 else (rate_16, min(16, ncpu), len(T_16), t_16)
-            out["cpu_baseline"] = {"value": best_rate, "unit": "registrations/s", "cores": best_cores, "kind": "port",
+            # thread sweep on two pairs each (the reference's reg_num_threads = 0 means "all cores"; on a many-core host fewer
+            # threads are faster for 64k points), then the sample at the best count
+            sweep = {}
+            for th in sorted({ncpu, 64, 32, 16, 8}):
+                if th <= ncpu:
+                    Ts, tt = cpu_run(th, 1e9, limit=2)
+                    sweep[th] = len(Ts) / tt
+            best_th = max(sweep, key=sweep.get)
+            T_cpu, t_cpu = cpu_run(best_th, args.cpu_seconds)
+            rate = len(T_cpu) / t_cpu
+            out["cpu_baseline"] = {"value": rate, "unit": "registrations/s", "cores": best_th, "kind": "port",
                                    "sample": "%d of the %d candidate pairs of one step (setInputTarget + align each; getFitnessScore not included), "
-                                             "oracle C++/OpenMP restatement, %.1f s; %d threads: %.2f/s, %d threads: %.2f/s"
-                                             % (best_n, P, best_t, ncpu, rate_all, min(16, ncpu), rate_16)}
-            out["speedup_vs_cpu_baseline"] = value / best_rate
-            # parity: GPU vs oracle, beside the oracle's own numerical band (same source, FMA contraction on)
-            T_fma, _ = cpu_run(ncpu, args.cpu_seconds, perturbed=True, limit=len(T_all))
-            n_cmp = min(len(T_all), len(T_fma))
-            eg = np.array([pose_error(records[c, 4:20].reshape(4, 4), T_all[c]) for c in range(n_cmp)])
-            eb = np.array([pose_error(T_fma[c], T_all[c]) for c in range(n_cmp)])
+                                             "oracle C++/OpenMP restatement, %.1f s at %d threads; 2-pair sweep reg/s by threads: %s"
+                                             % (len(T_cpu), P, t_cpu, best_th, {k: round(v, 2) for k, v in sweep.items()})}
+            out["speedup_vs_cpu_baseline"] = value / rate
+            # parity: GPU vs oracle, beside the oracle's own reproducibility (FMA-contracted twin, guess moved by +-1 ulp)
+            n_cmp = len(T_cpu)
+            twins = [cpu_run(best_th, 1e9, perturbed=True, limit=n_cmp)[0], cpu_run(best_th, 1e9, limit=n_cmp, ulps=1)[0],
+                     cpu_run(best_th, 1e9, limit=n_cmp, ulps=-1)[0]]
+            eg = np.array([pose_error(records[c, 4:20].reshape(4, 4), T_cpu[c]) for c in range(n_cmp)])
+            eb = np.array([[max(pose_error(tw[c], T_cpu[c])[k] for tw in twins) for k in (0, 1)] for c in range(n_cmp)])
             well = (eb[:, 0] <= 1e-4) & (eb[:, 1] <= 1e-5)
 
             def rms(a):
@@ -207,12 +220,13 @@ def main():
             out["pose_rmse_vs_oracle"] = {
                 "pairs": int(n_cmp), "translation_m": rms(eg[:, 0]), "rotation_rad": rms(eg[:, 1]),
                 "max_translation_m": float(eg[:, 0].max()), "max_rotation_rad": float(eg[:, 1].max()),
-                "well_conditioned_pairs": int(well.sum()),
-                "well_conditioned_translation_m": rms(eg[well, 0]), "well_conditioned_rotation_rad": rms(eg[well, 1]),
-                "well_conditioned_max_translation_m": float(eg[well, 0].max()) if well.any() else None,
-                "well_conditioned_max_rotation_rad": float(eg[well, 1].max()) if well.any() else None,
+                "reproducible_pairs": int(well.sum()),
+                "reproducible_translation_m": rms(eg[well, 0]), "reproducible_rotation_rad": rms(eg[well, 1]),
+                "reproducible_max_translation_m": float(eg[well, 0].max()) if well.any() else None,
+                "reproducible_max_rotation_rad": float(eg[well, 1].max()) if well.any() else None,
                 "oracle_self_band_translation_m": rms(eb[:, 0]), "oracle_self_band_rotation_rad": rms(eb[:, 1]),
-                "note": "well-conditioned = pairs on which the oracle and its FMA-contracted twin agree to 1e-4 m / 1e-5 rad"}
+                "note": "reproducible = pairs on which the oracle agrees with itself to 1e-4 m / 1e-5 rad when compiled with FMA "
+                        "contraction and when its float32 guess moves by +-1 ulp (DESIGN.md, NDT sensitivity)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

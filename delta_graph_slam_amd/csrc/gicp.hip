@@ -6,7 +6,7 @@
 // shipped launch file sets; object configured at src/hdl_graph_slam/registrations.cpp:27-36).  Algorithm: SURVEY.md App. B.
 //
 // MI355X design
-//   * No kd-trees: both clouds get the 8-ary Morton AABB index of nn_bvh.hip; k-NN covariances and the per-iteration
+//   * No kd-trees: both clouds get the 8-ary Hilbert-sorted AABB index of nn_bvh.hip; k-NN covariances and the per-iteration
 //     1-NN correspondences are searched by 8-lane groups (nn_group.h), exact and bounded by max_correspondence_distance.
 //   * One linearisation = correspond (8 lanes / point) + linearize (1 lane / point, all double: RCR = C_B + R C_A R^T,
 //     3x3 inverse, J = [skew(Tp) | -I], 21 + 6 + 1 sums) with the same wave-DPP -> LDS -> fixed-order partial rows as NDT,

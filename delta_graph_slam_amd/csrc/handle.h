@@ -17,14 +17,12 @@ struct Profiler {
   int64_t launches[DGS_K_COUNT] = {0};
 };
 
-// BVH over a point cloud (nn_bvh.hip): Morton-sorted points, implicit complete binary tree of AABBs.
+// Exact-NN index over a point cloud (nn_bvh.hip): Hilbert-sorted points, implicit complete 8-ary tree of AABBs.
 struct Bvh {
   int64_t n = 0;            // points
   int leaves = 0;           // number of leaf slots (power of two), each covers kLeafSize sorted points
   int levels = 0;
-  float org[3] = {0, 0, 0};  // Morton quantisation origin / scale
-  float scale = 1.f;
-  DevBuf<float4> sorted;    // points in Morton order, w = original index (bit-cast int)
+  DevBuf<float4> sorted;    // points in Hilbert order, w = original index (bit-cast int)
   DevBuf<float4> node_lo;   // AABB min per node (heap order, root = 0); w unused
   DevBuf<float4> node_hi;
   DevBuf<uint32_t> keys, keys_alt;

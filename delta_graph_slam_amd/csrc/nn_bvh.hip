@@ -9,8 +9,8 @@
 //
 // MI355X design.  A per-lane kd-tree walk is bound by the texture-addresser: every lane of a wave touches its own
 // cache line at every step (measured: 215 dependent steps x 3 uncoalesced 16-B loads per query, 0.68 ms per 64k
-// queries).  So the index is an 8-ARY implicit tree over Morton-sorted points and EIGHT LANES share one query:
-//   * points are sorted by 30-bit Morton code (one radix sort); a leaf is 8 consecutive points = one 128-B line;
+// queries).  So the index is an 8-ARY implicit tree over Hilbert-sorted points and EIGHT LANES share one query:
+//   * points are sorted by a 30-bit Hilbert index (one radix sort); a leaf is 8 consecutive points = one 128-B line;
 //   * an internal node stores its 8 children's AABBs contiguously (two 128-B lines), heap order, no pointers;
 //   * at a node each lane of the group tests one child box (the group reads exactly two full lines), the group
 //     ballots the children whose box is within the current best, descends nearest-first and keeps one pending-children
@@ -30,7 +30,7 @@
 namespace dgs {
 
 // ---- build ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict__ pts, int n, const float* __restrict__ mm6,
+__global__ __launch_bounds__(kBlock) void hilbert_key_kernel(const float4* __restrict__ pts, int n, const float* __restrict__ mm6,
                                                         uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(const float4* __restrict
   if (!(mm6[0] <= mm6[3])) { org[0] = org[1] = org[2] = 0.f; ext = 1.f; }
   const float scale = 1023.0f / ext;
   // non-finite points sort last and never win a query (their distance compares false)
-  keys[i] = (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) ? morton30(p.x, p.y, p.z, org, scale) : 0x3FFFFFFFu;
+  keys[i] = (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) ? hilbert30(p.x, p.y, p.z, org, scale) : 0x3FFFFFFFu;
   vals[i] = (uint32_t)i;
 }
 
@@ -193,7 +193,7 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st);
   DGS_HIP_TRY(h, h->cub_temp.reserve(tb + 256));
   const int nb = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, d_mm, bvh.keys.ptr, bvh.vals.ptr);
+  hipLaunchKernelGGL(hilbert_key_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, d_mm, bvh.keys.ptr, bvh.vals.ptr);
   tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st));
   hipLaunchKernelGGL(gather_index_kernel, dim3((n_pad + kBlock - 1) / kBlock), dim3(kBlock), 0, st, pts, bvh.vals_alt.ptr, n, n_pad, bvh.sorted.ptr);

@@ -12,7 +12,7 @@ constexpr int kLeaf = 8;    // points per leaf = lanes per query group
 constexpr int kFan = 8;     // children per node
 
 struct BvhView {
-  const float4* sorted;   // Morton order, padded to a multiple of 8; w = original index (bit pattern), -1 for padding
+  const float4* sorted;   // Hilbert order, padded to a multiple of 8; w = original index (bit pattern), -1 for padding
   const float4* box_lo;   // [node * 8 + child]
   const float4* box_hi;
   int n;
@@ -28,11 +28,29 @@ __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
   return v;
 }
 
-__device__ __forceinline__ uint32_t morton30(float x, float y, float z, const float* org, float scale) {
-  const float fx = fminf(fmaxf((x - org[0]) * scale, 0.f), 1023.f);
-  const float fy = fminf(fmaxf((y - org[1]) * scale, 0.f), 1023.f);
-  const float fz = fminf(fmaxf((z - org[2]) * scale, 0.f), 1023.f);
-  return (expand_bits10((uint32_t)fx) << 2) | (expand_bits10((uint32_t)fy) << 1) | expand_bits10((uint32_t)fz);
+// 30-bit 3-D HILBERT index of a point (10 bits per axis; Skilling's axes-to-transpose, then bit interleave).  Points are
+// sorted by this key: unlike the Z-curve the Hilbert curve has no jumps, so runs of 8 / 64 / 512 ... consecutive points
+// stay spatially compact and the AABBs of the implicit 8-ary tree overlap far less (55 -> ~15 node visits per query).
+__device__ __forceinline__ uint32_t hilbert30(float x, float y, float z, const float* org, float scale) {
+  uint32_t X0 = (uint32_t)fminf(fmaxf((x - org[0]) * scale, 0.f), 1023.f);
+  uint32_t X1 = (uint32_t)fminf(fmaxf((y - org[1]) * scale, 0.f), 1023.f);
+  uint32_t X2 = (uint32_t)fminf(fmaxf((z - org[2]) * scale, 0.f), 1023.f);
+  const uint32_t M = 1u << 9;
+#pragma unroll
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {  // inverse undo
+    const uint32_t P = Q - 1;
+    if (X0 & Q) X0 ^= P;  // i = 0: invert (the exchange branch is a no-op on X0 with itself)
+    if (X1 & Q) X0 ^= P; else { const uint32_t t = (X0 ^ X1) & P; X0 ^= t; X1 ^= t; }
+    if (X2 & Q) X0 ^= P; else { const uint32_t t = (X0 ^ X2) & P; X0 ^= t; X2 ^= t; }
+  }
+  X1 ^= X0;  // Gray encode
+  X2 ^= X1;
+  uint32_t t = 0;
+#pragma unroll
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (X2 & Q) t ^= Q - 1;
+  X0 ^= t; X1 ^= t; X2 ^= t;
+  return (expand_bits10(X0) << 2) | (expand_bits10(X1) << 1) | expand_bits10(X2);
 }
 
 __device__ __forceinline__ float sqdist_rn(float ax, float ay, float az, float bx, float by, float bz) {
@@ -77,8 +95,14 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
   unsigned long long pend = 0ull;  // one byte of not-yet-visited qualifying children per level
   bool fresh = true;
   bool done = !alive;
+#ifdef DGS_NN_STEPS
+  int n_nodes = 0, n_leaves = 0;
+#endif
   while (__any(!done)) {
     if (!done) {
+#ifdef DGS_NN_STEPS
+      n_nodes++;
+#endif
       const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
       const float d = aabb_sqdist_rn(lo, hi, x, y, z);
       // empty slots carry inverted boxes (distance +inf): never enter them, even while best is still +inf
@@ -91,6 +115,9 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
           const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
           const int c = (int)(group8_min_u32(key) & 7u);
           mask &= ~(1u << c);
+#ifdef DGS_NN_STEPS
+          n_leaves++;
+#endif
           const int leaf = (node * kFan + 1 + c) - b.first_leaf;
           const float4 p = b.sorted[leaf * kLeaf + sub];
           float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
@@ -131,6 +158,9 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
       }
     }
   }
+#ifdef DGS_NN_STEPS
+  best_idx = n_nodes * 1000 + n_leaves;
+#endif
 }
 
 
