@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--resolution", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget of the cpu_baseline sample")
+    ap.add_argument("--traffic", action="store_true",
+                    help="also measure HBM traffic of the dominant kernel: two child runs under rocprofv3 (--pmc FETCH_SIZE, then WRITE_SIZE)")
+    ap.add_argument("--traffic-dir", default=os.path.join(ROOT, "gpurun_out", "traffic"))
     args = ap.parse_args()
 
     import torch
@@ -227,10 +230,47 @@ def main():
                 "oracle_self_band_translation_m": rms(eb[:, 0]), "oracle_self_band_rotation_rad": rms(eb[:, 1]),
                 "note": "reproducible = pairs on which the oracle agrees with itself to 1e-4 m / 1e-5 rad when compiled with FMA "
                         "contraction and when its float32 guess moves by +-1 ulp (DESIGN.md, NDT sensitivity)"}
+        if world == 1 and args.traffic:
+            out["roofline"]["traffic"], out["roofline"]["traffic_detail"] = measure_traffic(args, bytes_per_eval)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_traffic(args, bytes_per_eval):
+    """HBM bytes per launch of ndt_derivatives from the PMC counters, as MI355X_MICROARCH.md (HBM / rocprofv3) prescribes:
+    FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), values in KiB, and on gfx950 FETCH_SIZE counts a wide coalesced
+    read at half its bytes, so the read side is doubled (an upper bound here: the kernel's gathers are not wide streams)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(args.traffic_dir, counter)
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d, exist_ok=True)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pairs", str(args.pairs),
+               "--points", str(args.points), "--distinct-scans", str(args.distinct_scans)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
+        tot, n = 0.0, 0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            per_dispatch = {}
+            for r in csv.DictReader(open(f)):
+                if "ndt_derivatives_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    per_dispatch[r["Dispatch_Id"]] = per_dispatch.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            tot += sum(per_dispatch.values())
+            n += len(per_dispatch)
+        res[counter] = (tot * 1024.0 / n) if n else None
+        res[counter + "_launches"] = n
+    if res["FETCH_SIZE"] is None or res["WRITE_SIZE"] is None:
+        return None, res
+    traffic = 2.0 * res["FETCH_SIZE"] + res["WRITE_SIZE"]
+    res["note"] = "bytes per launch averaged over all launches of the profiled child run (incl. launches whose pairs had finished)"
+    return traffic, res
 
 
 class _Sparse(list):
