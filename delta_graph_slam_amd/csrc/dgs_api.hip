@@ -172,7 +172,7 @@ void dgs_destroy(dgs_handle* h) {
   h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
-  h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->src_ptrs.release(); h->src_sizes.release();
+  h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
   h->target_bvh.sorted.release(); h->target_bvh.node_lo.release(); h->target_bvh.node_hi.release();
   h->target_bvh.keys.release(); h->target_bvh.keys_alt.release(); h->target_bvh.vals.release(); h->target_bvh.vals_alt.release();
   h->nn_partials.release(); h->scratch_cloud.release();

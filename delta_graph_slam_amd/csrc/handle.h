@@ -66,6 +66,7 @@ struct dgs_handle {
   dgs::DevBuf<dgs::NdtInit> inits;
   dgs::DevBuf<double> partials;       // [pair][block][kAccumPad]
   dgs::DevBuf<int> done_counter;      // [0] = finished pairs
+  dgs::DevBuf<int> pair_blocks;       // slices the last derivative launch gave each pair
   dgs::DevBuf<const float4*> src_ptrs;
   dgs::DevBuf<int> src_sizes;
   dgs::NdtConsts consts{};

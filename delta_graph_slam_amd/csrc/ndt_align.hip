@@ -6,7 +6,8 @@
 // src/hdl_graph_slam/registrations.cpp:105-119).  Algorithm: SURVEY.md App. A.
 //
 // MI355X design
-//   * One launch of ndt_derivatives covers EVERY pair of a batch (blockIdx.y = pair) and every source point:
+//   * One launch of ndt_derivatives covers EVERY still-active pair of a batch and every source point (its ~1024
+//     workgroups are re-dealt to the active pairs at each launch, on the device):
 //     coalesced 16-B loads of XYZ1 points, 7 (1/27) dependent 4-B cell lookups, 48-B voxel records from L2,
 //     float per-point math, double accumulation, wave shuffle -> LDS -> one 28-double partial row per block.
 //     No atomics: the rows are summed in a fixed order by ndt_solve, so results are bit-reproducible.
@@ -66,10 +67,40 @@ template <int SEARCH>
 __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
                                                                  const NdtPair* __restrict__ pairs, const VoxelGrid g, const float gd1,
                                                                  const float gd2, const int leaf_pow2, double* __restrict__ partials,
-                                                                 const int blocks_per_pair) {
-  const int pair = blockIdx.y;
+                                                                 const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks) {
+  // ---- map this workgroup to (still-active pair, slice).  The launch always has gridDim.x workgroups; they are dealt
+  // evenly to the pairs that are still iterating, so a batch whose pairs converge at different iterations keeps the chip
+  // busy on the stragglers instead of spinning up empty blocks.  Every wave derives the same mapping from the pairs'
+  // `active` words (written by the previous solve launch): one strided load + ballot per 64 pairs, no inter-block traffic.
+  const int lane_id = threadIdx.x & 63;
+  int n_active = 0;
+  for (int c0 = 0; c0 < n_pairs; c0 += 64) {
+    const int pi = c0 + lane_id;
+    const int a = (pi < n_pairs) ? pairs[pi].active : 0;
+    n_active += __popcll(__ballot(a != 0));
+  }
+  if (n_active == 0) return;
+  const int blocks_per_pair = min((int)gridDim.x / n_active, cap_blocks);
+  const int rank = blockIdx.x / blocks_per_pair, slice = blockIdx.x % blocks_per_pair;
+  if (rank >= n_active) return;
+  int pair = -1;
+  {
+    int seen = 0;
+    for (int c0 = 0; c0 < n_pairs && pair < 0; c0 += 64) {
+      const int pi = c0 + lane_id;
+      const int a = (pi < n_pairs) ? pairs[pi].active : 0;
+      unsigned long long m = __ballot(a != 0);
+      const int cnt = __popcll(m);
+      if (rank < seen + cnt) {
+        for (int k = rank - seen; k > 0; k--) m &= m - 1ull;  // drop the (rank - seen) lowest set bits
+        pair = c0 + __ffsll((long long)m) - 1;
+      }
+      seen += cnt;
+    }
+  }
+  pair = __builtin_amdgcn_readfirstlane(pair);
+  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
   const NdtPair& st = pairs[pair];
-  if (!st.active) return;
   const float4* __restrict__ src = src_ptrs[pair];
   const int n = src_sizes[pair];
   const bool need_h = st.need_hessian != 0;
@@ -83,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
   for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
 
   const float r2 = g.leaf * g.leaf;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
+  for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
     const float4 x = src[i];
     // pcl::transformPointCloud in float, ((m0 x + m1 y) + m2 z) + m3 with every step rounded (no FMA contraction):
     // q = x' - mean is a cancellation, so one ulp of x' is ~1e-5 of a point's contribution -- keep x' exact.
@@ -208,22 +239,44 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
   if (threadIdx.x < kAccumPad) {
     double v = 0.0;
     if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    partials[((size_t)pair * blocks_per_pair + blockIdx.x) * kAccumPad + threadIdx.x] = v;
+    partials[((size_t)pair * cap_blocks + slice) * kAccumPad + threadIdx.x] = v;
   }
 }
 
 // ================================================================================================ solver
 // float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap),
 // written to the pair's HBM record by lane 0 (`writer`); every lane computes the same values.
+// double sin/cos is software on the GPU (~100s of instructions per call) and an evaluation needs twelve of them; when the
+// whole wave runs this code with identical inputs (solve kernel), lane k evaluates angle k and the results are broadcast.
+template <bool WAVE>
+__device__ __forceinline__ void trig6(const double* ang, double* sn, double* cs) {
+  if (WAVE) {
+    const int lane = threadIdx.x & 63;
+    double a = ang[0];
+#pragma unroll
+    for (int k = 1; k < 6; k++) a = (lane == k) ? ang[k] : a;
+    double sv, cv;
+    sincos(a, &sv, &cv);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { sn[k] = __shfl(sv, k, 64); cs[k] = __shfl(cv, k, 64); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) sincos(ang[k], &sn[k], &cs[k]);
+  }
+}
+
+template <bool WAVE>
 __device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, const double* x, int need_hessian, bool write_T, bool writer) {
+  // angles 0..2: the FLOAT-rounded pose angles (transform entries), 3..5: the double pose angles (derivative tables)
+  const double ang[6] = {(double)(float)x[3], (double)(float)x[4], (double)(float)x[5], x[3], x[4], x[5]};
+  double sn[6], cs[6];
+  trig6<WAVE>(ang, sn, cs);
   if (write_T) {
     // Eigen builds Translation * AngleAxis(x) * AngleAxis(y) * AngleAxis(z) in float.  One ulp of a rotation entry moves
     // a point at 50 m by 3 um, which the q = x' - mean cancellation turns into ~1e-4 of that point's contribution, so
     // the entries are formed reproducibly: trig of the FLOAT angle evaluated in double and rounded once (what a
     // correctly rounded cosf/sinf returns), products individually rounded in the source order of the expression.
-    const float rx = (float)x[3], ry = (float)x[4], rz = (float)x[5];
-    const float cx = (float)cos((double)rx), sx = (float)sin((double)rx), cy = (float)cos((double)ry), sy = (float)sin((double)ry),
-                cz = (float)cos((double)rz), sz = (float)sin((double)rz);
+    const float cx = (float)cs[0], sx = (float)sn[0], cy = (float)cs[1], sy = (float)sn[1], cz = (float)cs[2], sz = (float)sn[2];
     const float r00 = mul_rn(cy, cz), r01 = mul_rn(-cy, sz), r02 = sy;
     const float r10 = add_rn(mul_rn(cx, sz), mul_rn(mul_rn(sx, sy), cz)), r11 = sub_rn(mul_rn(cx, cz), mul_rn(mul_rn(sx, sy), sz)), r12 = mul_rn(-sx, cy);
     const float r20 = sub_rn(mul_rn(sx, sz), mul_rn(mul_rn(cx, sy), cz)), r21 = add_rn(mul_rn(sx, cz), mul_rn(mul_rn(cx, sy), sz)), r22 = mul_rn(cx, cy);
@@ -240,9 +293,9 @@ __device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, 
     }
   }
   double cx, cy, cz, sx, sy, sz;
-  if (fabs(x[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cos(x[3]); sx = sin(x[3]); }
-  if (fabs(x[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cos(x[4]); sy = sin(x[4]); }
-  if (fabs(x[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cos(x[5]); sz = sin(x[5]); }
+  if (fabs(x[3]) < 10e-5) { cx = 1.0; sx = 0.0; } else { cx = cs[3]; sx = sn[3]; }
+  if (fabs(x[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cs[4]; sy = sn[4]; }
+  if (fabs(x[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cs[5]; sz = sn[5]; }
   if (writer) {
     float (*J)[3] = st->jang;
     J[0][0] = (float)(-sx * sz + cx * sy * cz); J[0][1] = (float)(-sx * cz - cx * sy * sz); J[0][2] = (float)(-cx * cy);
@@ -371,7 +424,7 @@ __device__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, b
   double x[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) x[k] = s.p[k] + s.dir[k] * a_t;
-  write_evaluation(st, s, c, x, 1, true, writer);
+  write_evaluation<true>(st, s, c, x, 1, true, writer);
   s.phase = PH_MT_FIRST;
   return true;
 }
@@ -407,7 +460,7 @@ __device__ void queue_trial(NdtPair* st, NdtSolver& s, const NdtConsts& c, doubl
   double x[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) x[k] = s.p[k] + s.dir[k] * a_t;
-  write_evaluation(st, s, c, x, 0, true, writer);
+  write_evaluation<true>(st, s, c, x, 0, true, writer);
   s.phase = PH_MT_TRIAL;
 }
 
@@ -452,7 +505,7 @@ __device__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool 
         double x[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) x[k] = s.x_t[k];
-        write_evaluation(st, s, c, x, 1, false, writer);
+        write_evaluation<true>(st, s, c, x, 1, false, writer);
         s.phase = PH_MT_HESSIAN;
         return;
       }
@@ -476,8 +529,8 @@ __device__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool 
   s.phase = PH_DONE;
 }
 
-__global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int blocks_per_pair,
-                                                           const NdtConsts c, int* __restrict__ done_counter) {
+__global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
+                                                           const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter) {
   const int pair = blockIdx.x;
   NdtPair* st = pairs + pair;
   if (!st->active) return;
@@ -486,7 +539,8 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
   const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
   constexpr int G = kBlock / kAccumPad;
   double v = 0.0;
-  const double* base = partials + (size_t)pair * blocks_per_pair * kAccumPad;
+  const int blocks_per_pair = pair_blocks[pair];  // slices the derivative launch gave this pair
+  const double* base = partials + (size_t)pair * cap_blocks * kAccumPad;
   for (int b = grp; b < blocks_per_pair; b += G) v += base[(size_t)b * kAccumPad + col];
   sm[grp][col] = v;
   __syncthreads();
@@ -548,7 +602,7 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   for (int k = 0; k < 36; k++) s.hess[k] = 0;
   double x[6];
   for (int k = 0; k < 6; k++) x[k] = in.p0[k];
-  write_evaluation(st, s, c, x, 1, false, true);
+  write_evaluation<false>(st, s, c, x, 1, false, true);
   // the first evaluation transforms the cloud by the GUESS matrix itself (computeTransformation)
   const float* G = in.guess;
   st->T[0] = G[0]; st->T[1] = G[4]; st->T[2] = G[8];  st->T[3] = G[12];
@@ -617,8 +671,14 @@ static void fill_consts(dgs_handle* h) {
   c.search_method = p.ndt_search_method;
 }
 
-static void launch_derivatives(dgs_handle* h, int n_pairs, int bpp) {
-  const dim3 grid(bpp, n_pairs), block(kBlock);
+struct NdtLaunch {
+  int n_pairs;
+  int cap_blocks;    // most slices one pair can get (= rows reserved per pair in `partials`)
+  int total_blocks;  // workgroups per derivative launch
+};
+
+static void launch_derivatives(dgs_handle* h, const NdtLaunch& L) {
+  const dim3 grid(L.total_blocks), block(kBlock);
   const float gd1 = (float)h->consts.gauss_d1, gd2 = (float)h->consts.gauss_d2;
   int fe = 0;
   const int leaf_pow2 = (std::frexp(h->grid.leaf, &fe) == 0.5f) ? 1 : 0;
@@ -626,50 +686,54 @@ static void launch_derivatives(dgs_handle* h, int n_pairs, int bpp) {
   switch (h->consts.search_method) {
     case DGS_NDT_DIRECT1:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT1>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
       break;
     case DGS_NDT_DIRECT26:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT26>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
       break;
     case DGS_NDT_KDTREE:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_KDTREE>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
       break;
     default:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT7>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, bpp);
+                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
       break;
   }
   prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
 }
 
-static void launch_solve(dgs_handle* h, int n_pairs, int bpp) {
+static void launch_solve(dgs_handle* h, const NdtLaunch& L) {
   int slot = prof_begin(h, DGS_K_NDT_SOLVE);
-  hipLaunchKernelGGL(ndt_solve_kernel, dim3(n_pairs), dim3(kBlock), 0, h->stream, h->pairs.ptr, h->partials.ptr, bpp, h->consts, h->done_counter.ptr);
+  hipLaunchKernelGGL(ndt_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->pairs.ptr, h->partials.ptr, L.cap_blocks, h->pair_blocks.ptr, h->consts,
+                     h->done_counter.ptr);
   prof_end(h, DGS_K_NDT_SOLVE, slot);
 }
 
-static int choose_blocks_per_pair(int n_pairs, int max_n) {
-  const int full = std::max(1, (max_n + kBlock - 1) / kBlock);     // one point per lane
-  const int share = std::max(8, 1024 / std::max(1, n_pairs));      // keep the whole launch near 1024 workgroups (4 per CU)
-  return std::max(1, std::min(std::min(full, share), kMaxPartialBlocks));
+static NdtLaunch choose_launch(int n_pairs, int max_n) {
+  NdtLaunch L;
+  L.n_pairs = n_pairs;
+  L.cap_blocks = std::max(1, std::min((max_n + kBlock - 1) / kBlock, 128));                 // at most 128 slices (partial rows) per pair
+  L.total_blocks = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_blocks, 1024));  // ~4 workgroups per CU
+  return L;
 }
 
-// Uploads pointers / sizes / initial poses, runs init, returns blocks-per-pair.
+// Uploads pointers / sizes / initial poses, runs init, returns the launch shape.
 static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_host, const int* sizes_host, const float* guesses16,
-                     const double* probe_p6, int* bpp_out) {
+                     const double* probe_p6, NdtLaunch* launch_out) {
   hipStream_t st = h->stream;
   fill_consts(h);
   int max_n = 0;
   for (int i = 0; i < n_pairs; i++) max_n = std::max(max_n, sizes_host[i]);
-  const int bpp = choose_blocks_per_pair(n_pairs, max_n);
-  *bpp_out = bpp;
+  const NdtLaunch L = choose_launch(n_pairs, max_n);
+  *launch_out = L;
   DGS_HIP_TRY(h, h->pairs.reserve(n_pairs));
   DGS_HIP_TRY(h, h->inits.reserve(n_pairs));
   DGS_HIP_TRY(h, h->src_ptrs.reserve(n_pairs));
   DGS_HIP_TRY(h, h->src_sizes.reserve(n_pairs));
-  DGS_HIP_TRY(h, h->partials.reserve((size_t)n_pairs * bpp * kAccumPad));
+  DGS_HIP_TRY(h, h->partials.reserve((size_t)n_pairs * L.cap_blocks * kAccumPad));
+  DGS_HIP_TRY(h, h->pair_blocks.reserve(n_pairs));
   DGS_HIP_TRY(h, h->done_counter.reserve(16));
   const size_t off_init = 256;
   const size_t off_ptr = off_init + sizeof(NdtInit) * n_pairs;
@@ -705,8 +769,8 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
 int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_host, const int* sizes_host, const float* guesses16,
                     dgs_result* results) {
   hipStream_t st = h->stream;
-  int bpp = 1;
-  int rc = ndt_setup(h, n_pairs, src_ptrs_host, sizes_host, guesses16, nullptr, &bpp);
+  NdtLaunch L{};
+  int rc = ndt_setup(h, n_pairs, src_ptrs_host, sizes_host, guesses16, nullptr, &L);
   if (rc != DGS_OK) return rc;
 
   // ---- iterate: chunks of (derivatives, solve) launches; the host looks at the done counter one chunk behind
@@ -717,12 +781,12 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
   const int per_iter = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
   const long max_evals = (long)(h->prm.maximum_iterations + 3) * per_iter + 2;
-  const int chunk = (n_pairs == 1) ? 6 : 8;
+  const int chunk = 4;  // (derivatives, solve) launches between two looks at the done counter
   long queued = 0;
   auto enqueue_chunk = [&](int slot) -> int {
     for (int e = 0; e < chunk; e++) {
-      launch_derivatives(h, n_pairs, bpp);
-      launch_solve(h, n_pairs, bpp);
+      launch_derivatives(h, L);
+      launch_solve(h, L);
     }
     queued += chunk;
     DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -787,7 +851,7 @@ int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len) {
 // Test hook: one computeDerivatives evaluation on the device.
 int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36) {
   hipStream_t st = h->stream;
-  int bpp = 1;
+  NdtLaunch L{};
   const float4* src = h->source.ptr;
   const int n = (int)h->ns;
   float T[16];
@@ -807,10 +871,10 @@ int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, 
     T[10] = mul(cx, cy); T[14] = (float)p6[2];
     T[3] = T[7] = T[11] = 0.f; T[15] = 1.f;
   }
-  int rc = ndt_setup(h, 1, &src, &n, T, p6, &bpp);
+  int rc = ndt_setup(h, 1, &src, &n, T, p6, &L);
   if (rc != DGS_OK) return rc;
-  launch_derivatives(h, 1, bpp);
-  launch_solve(h, 1, bpp);
+  launch_derivatives(h, L);
+  launch_solve(h, L);
   char* base = reinterpret_cast<char*>(h->pinned);
   NdtPair* hp = reinterpret_cast<NdtPair*>(base + ((h->pinned_bytes - sizeof(NdtPair) - 64) & ~(size_t)63));
   DGS_HIP_TRY(h, hipMemcpyAsync(hp, h->pairs.ptr, sizeof(NdtPair), hipMemcpyDeviceToHost, st));

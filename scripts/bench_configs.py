@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Measures every BASELINE.json config on one MI355X beside the CPU oracle (the numbers quoted in BASELINE.md / DESIGN.md).
+
+bench.py stays the driver's contract (configs[1] pairs in the configs[3] per-GPU batch); this script adds the other rows:
+  cfg1  16k planar pair, NDT 1.0 m            single align latency
+  cfg2  65,536-pt HDL-64E pair, NDT 1.0 m     single align latency (identity guess and odometry-like guess), ms per evaluation
+  cfg3  VLP-16 stream, FAST_GICP              per-frame latency p50 / p99 through the odometry driver (100 ms budget at 10 Hz)
+  cfg5  200k indoor pair, NDT 0.5 m           single align latency + ndt_derivatives GB/s (the HBM-stress row)
+Prints one JSON object per config.  usage: python scripts/bench_configs.py [--frames 100] [--cpu]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pose_error(Ta, Tb):
+    Ta = np.asarray(Ta, np.float64)
+    Tb = np.asarray(Tb, np.float64)
+    dt = np.linalg.norm(Ta[:3, 3] - Tb[:3, 3])
+    R = Ta[:3, :3].T @ Tb[:3, :3]
+    w = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return float(dt), float(np.arctan2(np.linalg.norm(w), 0.5 * (np.trace(R) - 1.0)))
+
+
+def timed(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
+def ndt_pair(name, tgt, src, res, guess, reps, cpu, orc, threads):
+    import torch
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd.registration import Registration
+    reg = Registration("NDT_OMP", ndt_resolution=res)
+    dt_, ds_ = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
+    t_set, _ = timed(lambda: reg.setInputTarget(dt_), reps)
+    reg.setInputSource(ds_)
+    t_align, _ = timed(lambda: reg.align(guess), reps)
+    t_fit, _ = timed(lambda: reg.getFitnessScore(), reps)
+    ev = reg.last_result.evaluations
+    reg.profile_enable(True)
+    reg.profile_reset()
+    for _ in range(reps):
+        reg.align(guess)
+    ms, n = reg.profile_get(L.K_NDT_DERIVATIVES)
+    ms_s, n_s = reg.profile_get(L.K_NDT_SOLVE)
+    reg.profile_enable(False)
+    c = reg.counts()
+    bytes_eval = 16 * src.shape[0] + 48 * c["valid_voxels"] + 344
+    out = {"config": name, "points": int(src.shape[0]), "resolution": res, "gpu_set_target_ms": 1e3 * t_set, "gpu_align_ms": 1e3 * t_align,
+           "gpu_fitness_ms": 1e3 * t_fit, "iterations": reg.last_result.iterations, "evaluations": ev, "converged": bool(reg.hasConverged()),
+           "gpu_ms_per_evaluation": 1e3 * t_align / max(ev, 1), "ndt_derivatives_us": 1e3 * ms / max(n, 1), "ndt_solve_us": 1e3 * ms_s / max(n_s, 1),
+           "ndt_derivatives_GBps": bytes_eval * ev * reps / (ms * 1e-3) / 1e9 if ms > 0 else None, "valid_voxels": c["valid_voxels"],
+           "gpu_registrations_per_s": 1.0 / t_align}
+    if cpu:
+        o = orc.NdtOracle(resolution=res, num_threads=threads)
+        o.set_target(tgt)
+        o.set_source(src)
+        ro = o.align(guess)
+        t_cpu, _ = timed(lambda: o.align(guess), 3, warm=1)
+        o1 = orc.NdtOracle(resolution=res, num_threads=1)
+        o1.set_target(tgt)
+        o1.set_source(src)
+        t_cpu1, _ = timed(lambda: o1.align(guess), 1, warm=0)
+        et, er = pose_error(reg.getFinalTransformation(), ro["T"])
+        out.update({"cpu_align_ms": 1e3 * t_cpu, "cpu_threads": threads, "cpu_align_ms_1thread": 1e3 * t_cpu1, "speedup": t_cpu / t_align,
+                    "vs_oracle_translation_m": et, "vs_oracle_rotation_rad": er, "oracle_iterations": ro["iterations"]})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+    import torch
+    from delta_graph_slam_amd import synth
+    from delta_graph_slam_amd.odometry import ScanMatchingOdometry
+    from delta_graph_slam_amd.registration import Registration
+    from oracle import oracle as orc
+    cpu = not args.no_cpu
+    th = min(args.cpu_threads, orc.max_threads())
+
+    tgt, src, Tgt = synth.planar_pair()
+    print(json.dumps(ndt_pair("cfg1 planar 16k, NDT 1.0 m, identity guess", tgt, src, 1.0, None, args.reps, cpu, orc, th)), flush=True)
+
+    tgt, src, Tgt = synth.kitti_pair()
+    print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, identity guess", tgt, src, 1.0, None, args.reps, cpu, orc, th)), flush=True)
+    g = Tgt.copy()
+    g[0, 3] -= 0.25
+    g[1, 3] += 0.10
+    print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, odometry-like guess (0.27 m off)", tgt, src, 1.0, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
+
+    tgt, src, Tgt = synth.indoor_pair()
+    print(json.dumps(ndt_pair("cfg5 indoor 200k pair, NDT 0.5 m, identity guess", tgt, src, 0.5, None, max(3, args.reps // 2), cpu, orc, th)), flush=True)
+
+    # ---- cfg3: VLP-16 stream through the odometry driver, FAST_GICP with the launch-file values
+    clouds, poses = synth.vlp16_stream(n_frames=args.frames)
+    dclouds = [torch.from_numpy(c).cuda() for c in clouds]
+    kw = dict(keyframe_delta_trans=1.0, keyframe_delta_angle=1.0, keyframe_delta_time=1e9)
+    odo = ScanMatchingOdometry(Registration("FAST_GICP", gicp_max_correspondence_distance=2.0, transformation_epsilon=0.1), kw)
+    lat = []
+    traj = []
+    for k, c in enumerate(dclouds):
+        t0 = time.perf_counter()
+        traj.append(odo.matching(0.1 * k, c))
+        lat.append(time.perf_counter() - t0)
+    lat_ms = 1e3 * np.array(lat[1:])
+    gt = [np.linalg.inv(poses[0]) @ p for p in poses]
+    drift = float(np.linalg.norm(traj[-1][:3, 3] - gt[-1][:3, 3]))
+    out = {"config": "cfg3 VLP-16 stream (%d frames, ~26k pts), FAST_GICP k=20 dmax 2.0 eps 0.1, odometry driver" % args.frames,
+           "gpu_frame_ms_p50": float(np.percentile(lat_ms, 50)), "gpu_frame_ms_p99": float(np.percentile(lat_ms, 99)), "gpu_frame_ms_max": float(lat_ms.max()),
+           "budget_ms": 100.0, "keyframes": odo.n_keyframes, "end_drift_m": drift, "path_length_m": float(np.linalg.norm(gt[-1][:3, 3]))}
+    if cpu:
+        from tests.oracle_engine import OracleRegistration
+        n_cpu = min(args.frames, 12)
+        oc = ScanMatchingOdometry(OracleRegistration("FAST_GICP", max_correspondence_distance=2.0, transformation_epsilon=0.1, num_threads=th), kw)
+        lc = []
+        errs = []
+        for k in range(n_cpu):
+            t0 = time.perf_counter()
+            T = oc.matching(0.1 * k, clouds[k])
+            lc.append(time.perf_counter() - t0)
+            errs.append(pose_error(traj[k], T))
+        out.update({"cpu_frame_ms_p50": float(1e3 * np.median(lc[1:])), "cpu_threads": th, "cpu_frames": n_cpu,
+                    "vs_oracle_max_translation_m": float(max(e[0] for e in errs)), "vs_oracle_max_rotation_rad": float(max(e[1] for e in errs)),
+                    "speedup_p50": float(np.median(lc[1:]) / (np.percentile(lat_ms, 50) * 1e-3))})
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -143,9 +143,11 @@ def test_batch_matches_single(reg_cls, oracle_lib):
     for k in range(5):
         r.setInputSource(sources[k])
         r.align(guesses[k])
-        assert np.array_equal(res[k]["T"], r.getFinalTransformation())   # bit-identical: same kernels, same order
+        # same kernels; only the number of partial rows per pair (fixed-order double sums) differs between batch and single
+        dt, dr = pose_error(res[k]["T"], r.getFinalTransformation())
+        assert dt <= 1e-6 and dr <= 1e-7
         assert res[k]["converged"] == r.hasConverged()
-        assert res[k]["fitness"] == r.getFitnessScore()
+        assert abs(res[k]["fitness"] - r.getFitnessScore()) <= 1e-6 * res[k]["fitness"]
         o.set_source(sources[k])
         ro = o.align(guesses[k])
         dt, dr = pose_error(res[k]["T"], ro["T"])
