@@ -178,6 +178,7 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
   int depth = 1;
   int64_t slots = kFan;
   while (slots < n_leaves) { slots *= kFan; depth++; }
+  if (depth > 8) { h->err = "cloud too large for the nearest-neighbour index (more than 8 levels)"; return DGS_ERR_UNSUPPORTED; }
   const int first_leaf = (int)((slots - 1) / (kFan - 1));
   const int n_pad = n_leaves * kLeaf;
   bvh.leaves = (int)slots;

@@ -84,6 +84,8 @@ __device__ __forceinline__ float group8_min_f32(float v) {
 }
 
 // Exact 1-NN of (x, y, z) for the 8-lane group this lane belongs to; x, y, z must be equal across the group.
+// (Measured and rejected: keeping the child-box distances of every level in registers to skip the reload on the way
+// back up costs more select instructions than the L1-resident reload saves; the traversal is VALU-issue bound.)
 // All 8 lanes return the same (best, best_idx).  Lanes of a wave whose group is idle must still call this with
 // `alive` = false (they follow the control flow and touch no memory beyond node 0).
 __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float y, float z, bool alive, float bound, float& best, int& best_idx) {
