@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -64,10 +65,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one process per GPU; DGS_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the multi-process path
+    backend = os.environ.get("DGS_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
     from delta_graph_slam_amd import _lib as L
     from delta_graph_slam_amd import synth
@@ -118,7 +125,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     regs = world * P * args.steps
@@ -135,26 +142,26 @@ def main():
                    "pairs_per_gpu": P, "points_per_scan": args.points, "parallelism": "candidates sharded one process per GPU, all_gather of result records"},
     }
 
+    # ---- roofline leg: the same steps with every ndt_derivatives launch bracketed by HIP events on its stream.  Every rank
+    # runs it (the step contains the all_gather), rank 0 reports its own kernel timings.
+    reg.profile_enable(True)
+    reg.profile_reset()
+    ev2 = 0
+    for _ in range(args.steps):
+        step()
+        ev2 += reg.counts()["evaluations"]
+    ms, launches = reg.profile_get(L.K_NDT_DERIVATIVES)
+    ms_solve, l_solve = reg.profile_get(L.K_NDT_SOLVE)
+    ms_nn, l_nn = reg.profile_get(L.K_NN_SEARCH)
+    ms_vox, l_vox = reg.profile_get(L.K_NDT_VOXEL_BUILD)
+    reg.profile_enable(False)
+
     if rank == 0:
         cnt = reg.counts()
         Ns, Nt, V = args.points, cnt["target_points"], cnt["valid_voxels"]
         out["ms_per_iter"] = 1e3 * dt / max(evals, 1) * P   # wall ms per derivative evaluation of one pair stream (P run concurrently)
         out["evaluations_per_registration"] = evals / (P * args.steps)
-        conv = float(np.mean(records[:, 1] > 0.5)) if records is not None else None
-        out["converged_fraction"] = conv
-
-        # ---- roofline leg: same steps with every ndt_derivatives launch bracketed by HIP events on its stream
-        reg.profile_enable(True)
-        reg.profile_reset()
-        ev2 = 0
-        for _ in range(args.steps):
-            step()
-            ev2 += reg.counts()["evaluations"]
-        ms, launches = reg.profile_get(L.K_NDT_DERIVATIVES)
-        ms_solve, l_solve = reg.profile_get(L.K_NDT_SOLVE)
-        ms_nn, l_nn = reg.profile_get(L.K_NN_SEARCH)
-        ms_vox, l_vox = reg.profile_get(L.K_NDT_VOXEL_BUILD)
-        reg.profile_enable(False)
+        out["converged_fraction"] = float(np.mean(records[:, 1] > 0.5)) if records is not None else None
         bytes_per_eval = 16 * Ns + 48 * V + 344            # stream source once, table once, 43 doubles out
         total_bytes = ev2 * bytes_per_eval
         achieved = total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
