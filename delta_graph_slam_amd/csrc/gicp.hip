@@ -61,10 +61,12 @@ __device__ void regularize_cov(const double* cov9, int method, double* out6) {
 // FastGICP::calculate_covariances: exact k-NN of every point in its own cloud, covariance of the neighbours, regularised
 __global__ __launch_bounds__(kBlock) void gicp_covariance_kernel(const BvhView b, const float4* __restrict__ pts, int n, int k, int method,
                                                                  double* __restrict__ cov6) {
+  // queries are taken in the index's own (Hilbert) order: the 8 groups of a wave then walk nearly the same nodes
   const int sub = threadIdx.x & 7;
-  const int i = (blockIdx.x * kBlock + threadIdx.x) >> 3;
-  const bool alive = i < n;
-  const float4 q = alive ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int pos = (blockIdx.x * kBlock + threadIdx.x) >> 3;
+  const float4 q = (pos < n) ? b.sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int i = (pos < n) ? (int)__float_as_uint(q.w) : -1;
+  const bool alive = pos < n && i >= 0 && i < n;
   KnnList L;
   knn_query_group(b, q.x, q.y, q.z, alive, k, L);
   if (!alive) return;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void gicp_covariance_kernel(const BvhView b
 // ================================================================================================ K5 correspondences
 // FastGICP::update_correspondences, search part: x' = float(T) * p in float, exact 1-NN in the target, accepted iff
 // d^2 < corr_dist_threshold^2
-__global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b, const float4* __restrict__ src, int n,
+__global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b, const float4* __restrict__ src_sorted, int n,
                                                                  const GicpPair* __restrict__ pairs, float max_sq, int* __restrict__ corr,
                                                                  float* __restrict__ corr_sq) {
   const GicpPair& st = pairs[0];
@@ -116,9 +118,11 @@ __global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b
   constexpr int QPB = kBlock / 8;
   const int sweeps = (n + gridDim.x * QPB - 1) / (gridDim.x * QPB);
   for (int sw = 0; sw < sweeps; sw++) {
-    const int i = (sw * gridDim.x + blockIdx.x) * QPB + (threadIdx.x >> 3);
-    const bool alive = i < n;
-    const float4 p = alive ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // source points in THEIR index's (Hilbert) order, w = original index: neighbouring groups query neighbouring places
+    const int pos = (sw * gridDim.x + blockIdx.x) * QPB + (threadIdx.x >> 3);
+    const float4 p = (pos < n) ? src_sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int i = (pos < n) ? (int)__float_as_uint(p.w) : -1;
+    const bool alive = pos < n && i >= 0 && i < n;
     const float x = affine_row_rn(T[0], T[1], T[2], T[3], p.x, p.y, p.z);
     const float y = affine_row_rn(T[4], T[5], T[6], T[7], p.x, p.y, p.z);
     const float z = affine_row_rn(T[8], T[9], T[10], T[11], p.x, p.y, p.z);
@@ -519,7 +523,7 @@ static void gicp_launch_round(dgs_handle* h, int nblocks) {
   const int n = (int)h->ns;
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
   const int cblocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)n * 8 + kBlock - 1) / kBlock, 4096));
-  hipLaunchKernelGGL(gicp_correspond_kernel, dim3(cblocks), dim3(kBlock), 0, h->stream, v, h->source.ptr, n, h->gpairs.ptr, h->gconsts.max_corr_sq,
+  hipLaunchKernelGGL(gicp_correspond_kernel, dim3(cblocks), dim3(kBlock), 0, h->stream, v, h->source_bvh.sorted.ptr, n, h->gpairs.ptr, h->gconsts.max_corr_sq,
                      h->corr.ptr, h->corr_sq.ptr);
   prof_end(h, DGS_K_NN_SEARCH, slot);
   slot = prof_begin(h, DGS_K_GICP_LINEARIZE);

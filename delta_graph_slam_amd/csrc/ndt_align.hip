@@ -227,13 +227,28 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
     }
   }
 
-  // ---- block reduction: wave shuffle -> LDS -> one row of kAccumPad doubles
+  // ---- block reduction.  A DPP butterfly over 28 doubles costs ~900 wave-instructions; instead every wave transposes
+  // through LDS, 14 values at a time: lane l stores value k at row k (stride 65 doubles: conflict-free both ways), then
+  // lane k adds the 64 entries of row k in lane order (fixed order -> reproducible).  ~290 wave-instructions.
+  constexpr int HALF = kAccum / 2, RS = 65;
+  __shared__ double tr[kBlock / kWave][HALF * RS];
   __shared__ double sm[kBlock / kWave][kAccumPad];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* my = tr[wave];
 #pragma unroll
-  for (int k = 0; k < kAccum; k++) {
-    const double v = wave_sum_to_lane63(acc[k]);
-    if (lane == 63) sm[wave][k] = v;
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int k = 0; k < HALF; k++) my[k * RS + lane] = acc[h * HALF + k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+    if (lane < HALF) {
+      double v = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 64; j++) v += my[lane * RS + j];
+      sm[wave][h * HALF + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
   }
   __syncthreads();
   if (threadIdx.x < kAccumPad) {
