@@ -178,6 +178,8 @@ void dgs_destroy(dgs_handle* h) {
   h->nn_partials.release(); h->scratch_cloud.release();
   h->source_bvh.sorted.release(); h->source_bvh.node_lo.release(); h->source_bvh.node_hi.release();
   h->source_bvh.keys.release(); h->source_bvh.keys_alt.release(); h->source_bvh.vals.release(); h->source_bvh.vals_alt.release();
+  h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
+  h->aux_bvh.keys.release(); h->aux_bvh.keys_alt.release(); h->aux_bvh.vals.release(); h->aux_bvh.vals_alt.release();
   h->cov_target.release(); h->cov_source.release(); h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
   for (auto& ep : h->prof.pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
   if (h->pinned) (void)hipHostFree(h->pinned);
@@ -471,6 +473,42 @@ int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, doubl
   if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
   if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
   return ndt_probe(h, p6, T16, score, grad6, hess36);
+}
+
+int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const float* cloud2, int64_t n2, int32_t on_device,
+                           const float* relpose16, double max_range, double* score) {
+  if (!h || !score || n1 < 0 || n2 < 0 || (n1 > 0 && !cloud1) || (n2 > 0 && !cloud2) || n1 > INT32_MAX || n2 > INT32_MAX) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  *score = DBL_MAX;
+  if (n1 == 0 || n2 == 0) return DGS_OK;  // no neighbour / no query: "nr == 0" branch of the reference
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  int rc = upload_cloud(h, h->aux_cloud1, cloud1, n1, on_device);
+  if (rc == DGS_OK) rc = upload_cloud(h, h->aux_cloud2, cloud2, n2, on_device);
+  if (rc == DGS_OK) rc = bvh_build(h, h->aux_bvh, h->aux_cloud1.ptr, n1);
+  if (rc != DGS_OK) return rc;
+  // stage pointer / size / transform exactly like the single-pair fitness path, but against the auxiliary index
+  hipStream_t st = h->stream;
+  DGS_HIP_TRY(h, h->src_ptrs.reserve(1));
+  DGS_HIP_TRY(h, h->src_sizes.reserve(1));
+  DGS_HIP_TRY(h, h->inits.reserve(1));
+  if (ensure_pinned(h, 8192) != DGS_OK) return DGS_ERR_HIP;
+  char* base = reinterpret_cast<char*>(h->pinned) + 2048;
+  const float4* src = h->aux_cloud2.ptr;
+  const int ni = (int)n2;
+  std::memcpy(base, &src, sizeof(void*));
+  std::memcpy(base + 16, &ni, sizeof(int));
+  std::memcpy(base + 64, relpose16 ? relpose16 : ident, sizeof(float) * 16);
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->src_ptrs.ptr, base, sizeof(void*), hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->src_sizes.ptr, base + 16, sizeof(int), hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, base + 64, sizeof(float) * 16, hipMemcpyHostToDevice, st));
+  double sum = 0;
+  int64_t cnt = 0, inl = 0;
+  rc = nn_fitness_batch_on(h, h->aux_bvh, 1, h->src_ptrs.ptr, h->src_sizes.ptr, ni, reinterpret_cast<const float*>(h->inits.ptr), 64, max_range, 0.0,
+                           &sum, &cnt, &inl);
+  if (rc != DGS_OK) return rc;
+  *score = cnt > 0 ? sum / (double)cnt : DBL_MAX;
+  return DGS_OK;
 }
 
 int dgs_gicp_get_covariances(dgs_handle* h, int32_t which, double* cov9) {

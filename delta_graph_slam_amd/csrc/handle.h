@@ -85,6 +85,11 @@ struct dgs_handle {
   dgs::DevBuf<double> nn_partials;
   dgs::DevBuf<float4> scratch_cloud;
 
+  // ---- calc_fitness_score between two arbitrary clouds (InformationMatrixCalculator): own buffers, the registration's
+  // target / source / result are left untouched
+  dgs::DevBuf<float4> aux_cloud1, aux_cloud2;
+  dgs::Bvh aux_bvh;
+
   // ---- GICP (fast_gicp::FastGICP): k-NN covariances of both clouds, correspondences, Mahalanobis matrices
   dgs::Bvh source_bvh;
   dgs::DevBuf<double> cov_target, cov_source;  // 6 doubles per point: xx, xy, xz, yy, yz, zz
@@ -121,6 +126,8 @@ int nn_fitness(dgs_handle* h, const float4* src, int64_t n, const float* T16, do
 // batched: device arrays of source pointers / sizes, device transforms (column-major 16 floats every T_stride_bytes)
 int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
+int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
+                        const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
 // gicp.hip
 int gicp_align(dgs_handle* h, const float* guess16, dgs_result* out);

@@ -244,8 +244,13 @@ int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
   int rc = ensure_target_bvh(h);
   if (rc) return rc;
+  return nn_fitness_batch_on(h, h->target_bvh, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, max_range, inlier_sq, sums, counts, inliers);
+}
+
+int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
+                        size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
   hipStream_t st = h->stream;
-  const BvhView v = make_bvh_view(h->target_bvh);
+  const BvhView v = make_bvh_view(index);
   const int full = std::max(1, (int)(((int64_t)max_size * 8 + kBlock - 1) / kBlock));  // one query per 8 lanes
   const int bpp = std::max(1, std::min(full, std::max(64, 8192 / std::max(1, n_pairs))));
   DGS_HIP_TRY(h, h->nn_partials.reserve((size_t)n_pairs * bpp * 4 + (size_t)n_pairs * 4));

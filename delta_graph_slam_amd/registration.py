@@ -168,6 +168,18 @@ class Registration:
         self._check(self._lib.dgs_nearest_search_target(self._h, ptr, m, 0, idx.ctypes.data_as(C.c_void_p), sq.ctypes.data_as(C.c_void_p)))
         return idx, sq
 
+    def calc_fitness_score(self, cloud1, cloud2, relpose=None, max_range: float = 1.7976931348623157e308) -> float:
+        """InformationMatrixCalculator::calc_fitness_score (information_matrix_calculator.cpp:77-108) on the device."""
+        p1, n1, d1, k1 = _cloud_ptr(cloud1)
+        p2, n2, d2, k2 = _cloud_ptr(cloud2)
+        if n1 and n2 and d1 != d2:
+            raise ValueError("both clouds must live on the same side (host arrays or device tensors)")
+        t = None if relpose is None else _col16(relpose)
+        s = C.c_double(0)
+        self._check(self._lib.dgs_calc_fitness_score(self._h, p1, n1, p2, n2, d1 if n1 else d2, None if t is None else t.ctypes.data_as(C.c_void_p),
+                                                      max_range, C.byref(s)))
+        return s.value
+
     # -- batched candidates (loop_detector.hpp:137-156) ----------------------------------------------------
     def align_batch(self, sources, guesses=None, compute_fitness: bool = True, fitness_max_range: float = 1.7976931348623157e308):
         n = len(sources)

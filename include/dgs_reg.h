@@ -160,6 +160,14 @@ int dgs_nearest_search_target(dgs_handle* h, const float* queries_xyz16, int64_t
 int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const int64_t* sizes, int32_t on_device,
                     const float* guesses16, int32_t compute_fitness, double fitness_max_range, dgs_result* results);
 
+/* InformationMatrixCalculator::calc_fitness_score(cloud1, cloud2, relpose, max_range)
+ * (/root/reference/src/hdl_graph_slam/information_matrix_calculator.cpp:77-108; called per odometry edge and per loop
+ * edge, apps/delta_graph_slam_nodelet.cpp:572,820): exact-NN index over cloud1, cloud2 transformed by the float cast of
+ * relpose (column-major 16 floats, NULL = identity), mean squared NN distance over points with d^2 <= max_range, DBL_MAX
+ * when none qualifies.  Uses buffers of its own: the handle's registration target / source / result are untouched. */
+int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1_xyz16, int64_t n1, const float* cloud2_xyz16, int64_t n2,
+                           int32_t on_device, const float* relpose16, double max_range, double* score);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) ---------------------- */
 enum dgs_kernel_id {
   DGS_K_NDT_DERIVATIVES = 0, DGS_K_NDT_SOLVE = 1, DGS_K_NDT_VOXEL_BUILD = 2, DGS_K_NN_SEARCH = 3,

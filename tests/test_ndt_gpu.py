@@ -162,3 +162,28 @@ def test_errors_surface_as_not_converged(reg_cls):
     r.setInputTarget(tgt)
     assert r.align() is None and not r.hasConverged()       # no source
     assert np.array_equal(r.getFinalTransformation(), np.eye(4, dtype=np.float32))
+
+
+def test_calc_fitness_score_between_two_clouds(reg_cls, oracle_lib):
+    """SURVEY §8f-1: InformationMatrixCalculator::calc_fitness_score on the device == the oracle's PCL loop."""
+    from delta_graph_slam_amd.information_matrix import InformationMatrixCalculator
+    tgt, src, Tgt = synth.planar_pair(n=8192)
+    r = reg_cls("NDT_OMP", ndt_resolution=1.0)
+    r.setInputTarget(src)                                    # the registration's own state must survive the auxiliary call
+    r.setInputSource(tgt)
+    r.align()
+    T_before, fit_before = r.getFinalTransformation(), r.getFitnessScore()
+    for mr in (1.7976931348623157e308, 0.05):
+        fo, n, _ = oracle_lib.fitness_score(tgt, src, Tgt.astype(np.float32), mr)
+        fg = r.calc_fitness_score(tgt, src, Tgt, mr)
+        assert abs(fg - fo) <= 1e-12 * fo
+    assert r.calc_fitness_score(tgt, src, Tgt, -1.0) == 1.7976931348623157e308
+    assert r.calc_fitness_score(tgt, np.zeros((0, 4), np.float32), Tgt) == 1.7976931348623157e308
+    assert np.array_equal(r.getFinalTransformation(), T_before) and r.getFitnessScore() == fit_before
+    calc = InformationMatrixCalculator({}, registration=r)
+    inf = calc.calc_information_matrix(tgt, src, Tgt)
+    fo, _, _ = oracle_lib.fitness_score(tgt, src, Tgt.astype(np.float32))
+    wx = calc.weight(20.0, 0.5, 0.1 ** 2, 5.0 ** 2, fo)
+    assert inf.shape == (3, 3) and abs(inf[0, 0] - 1.0 / np.float32(wx)) < 1e-9 and inf[0, 1] == 0
+    const = InformationMatrixCalculator({"use_const_inf_matrix": True}).calc_information_matrix(None, None, None)
+    assert np.allclose(np.diag(const), [2.0, 2.0, 10.0])
