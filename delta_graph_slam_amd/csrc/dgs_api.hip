@@ -178,7 +178,7 @@ void dgs_destroy(dgs_handle* h) {
   h->nn_partials.release(); h->scratch_cloud.release();
   h->source_bvh.sorted.release(); h->source_bvh.node_lo.release(); h->source_bvh.node_hi.release();
   h->source_bvh.keys.release(); h->source_bvh.keys_alt.release(); h->source_bvh.vals.release(); h->source_bvh.vals_alt.release();
-  h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
+  h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_out.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
   h->aux_bvh.keys.release(); h->aux_bvh.keys_alt.release(); h->aux_bvh.vals.release(); h->aux_bvh.vals_alt.release();
   h->cov_target.release(); h->cov_source.release(); h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
   for (auto& ep : h->prof.pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
@@ -508,6 +508,41 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const
                            &sum, &cnt, &inl);
   if (rc != DGS_OK) return rc;
   *score = cnt > 0 ? sum / (double)cnt : DBL_MAX;
+  return DGS_OK;
+}
+
+int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
+                          int64_t out_capacity, int32_t out_on_device, int64_t* n_out) {
+  if (!h || !n_out || n < 0 || (n > 0 && (!in_xyz16 || !out_xyz16)) || n > INT32_MAX || !(leaf_size > 0) || out_capacity < 0) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  *n_out = 0;
+  if (n == 0) return DGS_OK;
+  const float4* din = reinterpret_cast<const float4*>(in_xyz16);
+  if (!in_on_device) {
+    int rc = upload_cloud(h, h->aux_cloud1, in_xyz16, n, 0);
+    if (rc) return rc;
+    din = h->aux_cloud1.ptr;
+  }
+  float4* dout = reinterpret_cast<float4*>(out_xyz16);
+  int64_t cap = out_capacity;
+  if (!out_on_device) {
+    DGS_HIP_TRY(h, h->aux_out.reserve((size_t)n));
+    dout = h->aux_out.ptr;
+    cap = n;
+  }
+  int64_t m = 0;
+  int rc = voxel_grid_filter(h, din, n, leaf_size, dout, cap, &m);
+  if (rc) return rc;
+  *n_out = m;
+  if (m > out_capacity) {
+    h->err = "output buffer too small for the filtered cloud";
+    return DGS_ERR_INVALID_ARGUMENT;
+  }
+  if (!out_on_device && m > 0) {
+    DGS_HIP_TRY(h, hipMemcpyAsync(out_xyz16, dout, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
   return DGS_OK;
 }
 

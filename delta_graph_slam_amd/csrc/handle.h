@@ -87,7 +87,7 @@ struct dgs_handle {
 
   // ---- calc_fitness_score between two arbitrary clouds (InformationMatrixCalculator): own buffers, the registration's
   // target / source / result are left untouched
-  dgs::DevBuf<float4> aux_cloud1, aux_cloud2;
+  dgs::DevBuf<float4> aux_cloud1, aux_cloud2, aux_out;
   dgs::Bvh aux_bvh;
 
   // ---- GICP (fast_gicp::FastGICP): k-NN covariances of both clouds, correspondences, Mahalanobis matrices
@@ -112,6 +112,7 @@ int ensure_pinned(dgs_handle* h, size_t bytes);
 
 // ndt_voxel.hip
 int ndt_build_target(dgs_handle* h);
+int voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, float4* out, int64_t out_capacity, int64_t* n_out);
 int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]);
 int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6);
 // ndt_align.hip

@@ -192,6 +192,91 @@ __global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __
   if (valid) atomicAdd(&scalars[1], 1);
 }
 
+// ---- pcl::VoxelGrid centroid filter: one lane per occupied cell, float sums in point-index order ------
+__global__ __launch_bounds__(kBlock) void voxel_centroid_kernel(const float4* __restrict__ sorted_pts, const uint32_t* __restrict__ run_keys,
+                                                                const int* __restrict__ run_counts, const int* __restrict__ run_offsets,
+                                                                const int* __restrict__ scalars, float4* __restrict__ out, int out_capacity) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= scalars[0] || r >= out_capacity) return;
+  if (run_keys[r] == 0xFFFFFFFFu) return;  // the run of non-finite points sorts last: it is simply not emitted
+  const int off = run_offsets[r], cnt = run_counts[r];
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int j = 0; j < cnt; j++) {
+    const float4 p = sorted_pts[off + j];
+    sx += p.x; sy += p.y; sz += p.z;
+  }
+  const float fn = (float)cnt;
+  out[r] = make_float4(sx / fn, sy / fn, sz / fn, 1.f);
+}
+
+__global__ void voxel_count_kernel(const uint32_t* __restrict__ run_keys, int* __restrict__ scalars) {
+  // number of emitted cells = runs, minus the trailing run of non-finite points if there is one
+  const int nr = scalars[0];
+  scalars[2] = (nr > 0 && run_keys[nr - 1] == 0xFFFFFFFFu) ? nr - 1 : nr;
+}
+
+// out receives the centroids ordered by cell index (as pcl::VoxelGrid emits them); *n_out the number of cells.
+int voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, float4* out, int64_t out_capacity, int64_t* n_out) {
+  hipStream_t st = h->stream;
+  *n_out = 0;
+  if (n == 0) return DGS_OK;
+  float hmm[6];
+  int rc = cloud_minmax(h, in, n, hmm);
+  if (rc) return rc;
+  if (!(hmm[0] <= hmm[3])) return DGS_OK;
+  VoxelGrid g{};
+  g.leaf = leaf;
+  g.inv_leaf = 1.0f / leaf;
+  int64_t cells = 1;
+  for (int a = 0; a < 3; a++) {
+    g.min_b[a] = (int)std::floor(hmm[a] * g.inv_leaf);
+    g.max_b[a] = (int)std::floor(hmm[3 + a] * g.inv_leaf);
+    g.div_b[a] = g.max_b[a] - g.min_b[a] + 1;
+    cells *= (int64_t)((hmm[3 + a] - hmm[a]) * g.inv_leaf) + 1;
+  }
+  if (cells > INT32_MAX || (int64_t)g.div_b[0] * g.div_b[1] * g.div_b[2] > INT32_MAX) {
+    h->err = "Leaf size is too small for the input dataset. Integer indices would overflow.";
+    return DGS_ERR_GRID_TOO_LARGE;
+  }
+  g.mul1 = g.div_b[0];
+  g.mul2 = g.div_b[0] * g.div_b[1];
+  DGS_HIP_TRY(h, h->key_in.reserve(n));
+  DGS_HIP_TRY(h, h->key_out.reserve(n));
+  DGS_HIP_TRY(h, h->val_in.reserve(n));
+  DGS_HIP_TRY(h, h->val_out.reserve(n));
+  DGS_HIP_TRY(h, h->run_keys.reserve(n));
+  DGS_HIP_TRY(h, h->run_counts.reserve(n));
+  DGS_HIP_TRY(h, h->run_offsets.reserve(n));
+  DGS_HIP_TRY(h, h->dev_scalars.reserve(8));
+  DGS_HIP_TRY(h, h->scratch_cloud.reserve(n));
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0, 32, st);
+  (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, h->key_out.ptr, h->run_keys.ptr, h->run_counts.ptr, h->dev_scalars.ptr, (int)n, st);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t3, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st);
+  DGS_HIP_TRY(h, h->cub_temp.reserve(std::max(t1, std::max(t2, t3)) + 256));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->dev_scalars.ptr, 0, 8 * sizeof(int), st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->run_counts.ptr, 0, (size_t)n * sizeof(int), st));
+  const int nb = (int)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, in, n, g, h->key_in.ptr, h->val_in.ptr);
+  size_t tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0, 32, st));
+  tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceRunLengthEncode::Encode(h->cub_temp.ptr, tb, h->key_out.ptr, h->run_keys.ptr, h->run_counts.ptr, h->dev_scalars.ptr, (int)n, st));
+  tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceScan::ExclusiveSum(h->cub_temp.ptr, tb, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st));
+  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(kBlock), 0, st, in, h->val_out.ptr, n, h->scratch_cloud.ptr);
+  hipLaunchKernelGGL(voxel_centroid_kernel, dim3(nb), dim3(kBlock), 0, st, h->scratch_cloud.ptr, h->run_keys.ptr, h->run_counts.ptr, h->run_offsets.ptr,
+                     h->dev_scalars.ptr, out, (int)std::min<int64_t>(out_capacity, INT32_MAX));
+  hipLaunchKernelGGL(voxel_count_kernel, dim3(1), dim3(1), 0, st, h->run_keys.ptr, h->dev_scalars.ptr);
+  int* hs = reinterpret_cast<int*>(h->pinned);
+  DGS_HIP_TRY(h, hipMemcpyAsync(hs, h->dev_scalars.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipStreamSynchronize(st));
+  DGS_HIP_TRY(h, hipGetLastError());
+  *n_out = hs[2];
+  h->counts_stale = true;
+  return DGS_OK;
+}
+
 // ---- host driver -------------------------------------------------------------------------------------------
 int ndt_build_target(dgs_handle* h) {
   const int64_t n = h->nt;

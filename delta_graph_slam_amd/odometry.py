@@ -6,7 +6,8 @@ Mirrors /root/reference/apps/scan_matching_odometry_nodelet.cpp:
   matching            :173-270  first frame -> keyframe + setInputTarget; else setInputSource, align(prev_trans * msf_delta),
                                 reject on !hasConverged (:222-226) or implausible jump (:231-241), keyframe switch (:249-260)
   publish_scan_matching_status :309-346  matching_error = getFitnessScore(), inlier_fraction (d^2 < 0.25)
-Down-sampling (:155-165) happens upstream of the hot path and is the caller's business here.
+Down-sampling (:83-103,155-165): VOXELGRID runs on the device (pcl::VoxelGrid centroid filter, SURVEY.md §8f-2) so a raw scan
+uploaded once stays in HBM through align; NONE passes the cloud through; APPROX_VOXELGRID is not provided.
 
 The frame loop is inherently sequential (frame t's guess is frame t-1's result), so this path does not shard:
 "replicas only"  -- one stream per GPU if several robots / bags are processed.
@@ -50,6 +51,12 @@ class ScanMatchingOdometry:
         self.transform_thresholding = bool(pr.get("transform_thresholding", False))
         self.max_acceptable_trans = float(pr.get("max_acceptable_trans", 1.0))
         self.max_acceptable_angle = float(pr.get("max_acceptable_angle", 1.0))
+        # the reference defaults to VOXELGRID 0.1 m (:83-84); the mirror defaults to NONE so callers that already filtered are not
+        # filtered twice -- pass downsample_method explicitly to reproduce the nodelet
+        self.downsample_method = str(pr.get("downsample_method", "NONE"))
+        self.downsample_resolution = float(pr.get("downsample_resolution", 0.1))
+        if self.downsample_method == "APPROX_VOXELGRID":
+            raise NotImplementedError("APPROX_VOXELGRID is not provided; use VOXELGRID or NONE")
         if registration is None:
             from .registration import select_registration_method
             registration = select_registration_method(pr, device=device)
@@ -62,6 +69,12 @@ class ScanMatchingOdometry:
         self.last_status: Optional[ScanMatchingStatus] = None
         self.n_keyframes = 0
 
+    def downsample(self, cloud):
+        """scan_matching_odometry_nodelet.cpp:155-165"""
+        if self.downsample_method == "VOXELGRID":
+            return self.registration.voxel_grid_filter(cloud, self.downsample_resolution)
+        return cloud
+
     def matching(self, stamp: float, cloud, msf_delta: Optional[np.ndarray] = None, want_status: bool = False) -> np.ndarray:
         """Returns odom (4x4 float32): the pose of this frame in the odometry frame."""
         reg = self.registration
@@ -70,12 +83,13 @@ class ScanMatchingOdometry:
             self.prev_trans = np.eye(4, dtype=np.float32)
             self.keyframe_pose = np.eye(4, dtype=np.float32)
             self.keyframe_stamp = stamp
-            self.keyframe = cloud
-            reg.setInputTarget(cloud)
+            self.keyframe = self.downsample(cloud)
+            reg.setInputTarget(self.keyframe)
             self.n_keyframes = 1
             return np.eye(4, dtype=np.float32)
 
-        reg.setInputSource(cloud)
+        filtered = self.downsample(cloud)
+        reg.setInputSource(filtered)
         delta = np.eye(4, dtype=np.float32) if msf_delta is None else np.asarray(msf_delta, np.float32)
         reg.align((self.prev_trans @ delta).astype(np.float32))
 
@@ -103,8 +117,8 @@ class ScanMatchingOdometry:
         delta_angle = float(np.arccos(np.clip(_quat_w(trans[:3, :3]), -1.0, 1.0)))
         delta_time = stamp - self.keyframe_stamp
         if delta_trans > self.keyframe_delta_trans or delta_angle > self.keyframe_delta_angle or delta_time > self.keyframe_delta_time:
-            self.keyframe = cloud
-            reg.setInputTarget(cloud)
+            self.keyframe = filtered
+            reg.setInputTarget(filtered)
             self.keyframe_pose = odom
             self.keyframe_stamp = stamp
             self.prev_time = stamp

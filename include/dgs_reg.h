@@ -168,6 +168,14 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
 int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1_xyz16, int64_t n1, const float* cloud2_xyz16, int64_t n2,
                            int32_t on_device, const float* relpose16, double max_range, double* score);
 
+/* pcl::VoxelGrid<PointXYZ> centroid down-sampling, the step right before the path
+ * (/root/reference/apps/scan_matching_odometry_nodelet.cpp:83-89,155-165; apps/prefiltering_nodelet.cpp:59-63):
+ * cell = floor(p / leaf) as PCL indexes it, output = centroid of every occupied cell in cell-index order, pad lane = 1.
+ * Sums are formed in float in point-index order (PCL's std::sort leaves the order inside a cell unspecified).
+ * `*n_out` receives the number of cells; fails with DGS_ERR_INVALID_ARGUMENT when out_capacity is smaller. */
+int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
+                          int64_t out_capacity, int32_t out_on_device, int64_t* n_out);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) ---------------------- */
 enum dgs_kernel_id {
   DGS_K_NDT_DERIVATIVES = 0, DGS_K_NDT_SOLVE = 1, DGS_K_NDT_VOXEL_BUILD = 2, DGS_K_NN_SEARCH = 3,

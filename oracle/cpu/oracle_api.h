@@ -56,6 +56,8 @@ double orc_fitness_score(const float* target, int64_t nt, const float* source, i
                          double inlier_sq, int64_t* n_used, int64_t* n_inliers);
 void orc_knn(const float* cloud, int64_t n, const float* queries, int64_t m, int32_t k, int32_t* idx, float* d2);
 void orc_se3_exp(const double* a6, double* T16_rowmajor);
+/* pcl::VoxelGrid centroid filter; out must hold n points; returns the number of cells */
+int64_t orc_voxel_grid(const float* xyz16, int64_t n, float leaf, float* out_xyz16);
 
 #ifdef __cplusplus
 }

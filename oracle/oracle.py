@@ -325,3 +325,13 @@ def se3_exp(a):
     T = np.zeros((4, 4))
     lib().orc_se3_exp(pa, T.ctypes.data_as(C.POINTER(C.c_double)))
     return T
+
+
+def voxel_grid(cloud, leaf: float) -> np.ndarray:
+    """pcl::VoxelGrid centroid filter (restatement in oracle/cpu/voxelgrid_cpu.cpp)."""
+    c, pc = _f32c(cloud)
+    out = np.empty((max(c.shape[0], 1), 4), np.float32)
+    L = lib()
+    L.orc_voxel_grid.restype = C.c_int64
+    m = L.orc_voxel_grid(pc, C.c_int64(c.shape[0]), C.c_float(leaf), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:m].copy()

@@ -187,3 +187,19 @@ def test_calc_fitness_score_between_two_clouds(reg_cls, oracle_lib):
     assert inf.shape == (3, 3) and abs(inf[0, 0] - 1.0 / np.float32(wx)) < 1e-9 and inf[0, 1] == 0
     const = InformationMatrixCalculator({"use_const_inf_matrix": True}).calc_information_matrix(None, None, None)
     assert np.allclose(np.diag(const), [2.0, 2.0, 10.0])
+
+
+@pytest.mark.parametrize("leaf", [0.1, 0.25, 1.0])
+def test_voxel_grid_filter_matches_oracle(reg_cls, oracle_lib, leaf):
+    """SURVEY §8f-2: pcl::VoxelGrid centroid down-sampling on the device, bit-exact against the restatement."""
+    import torch
+    xyz, _ = synth.street_scan((0.0, 0.0, 0.0), 64, (2.0, -24.8), 1024, 5)
+    cloud = synth._xyz1(xyz)
+    cloud[11, 1] = np.nan                                   # non-finite points are dropped, as with is_dense = false
+    r = reg_cls("NDT_OMP")
+    ref = oracle_lib.voxel_grid(cloud, leaf)
+    out = r.voxel_grid_filter(cloud, leaf)
+    assert out.shape == ref.shape and np.array_equal(out, ref)           # same cells, same order, same float sums
+    dout = r.voxel_grid_filter(torch.from_numpy(cloud).cuda(), leaf)     # device in -> device out
+    assert dout.is_cuda and np.array_equal(dout.cpu().numpy(), ref)
+    assert r.voxel_grid_filter(np.zeros((0, 4), np.float32), leaf).shape == (0, 4)
