@@ -1,5 +1,6 @@
 // C ABI of libdgs_reg.so (include/dgs_reg.h).  Thin: argument checks, device/stream plumbing, uploads, and
 // dispatch into the kernels' host drivers.  No exception ever crosses this boundary.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstddef>
@@ -103,6 +104,20 @@ static int upload_cloud(dgs_handle* h, DevBuf<float4>& buf, const float* xyz16, 
   return DGS_OK;
 }
 
+// a handle borrows at most two dgs_cloud objects (target, source); both sides keep a back reference so that either may go first
+static void unbind(dgs_handle* h, dgs_cloud*& slot) {
+  if (!slot) return;
+  dgs_cloud* c = slot;
+  slot = nullptr;
+  if (h->tgt_cloud != c && h->src_cloud != c) c->users.erase(std::remove(c->users.begin(), c->users.end(), h), c->users.end());
+}
+static void bind(dgs_handle* h, dgs_cloud*& slot, dgs_cloud* c) {
+  if (slot == c) return;
+  unbind(h, slot);
+  if (std::find(c->users.begin(), c->users.end(), h) == c->users.end()) c->users.push_back(h);
+  slot = c;
+}
+
 static thread_local std::string g_create_error;  // dgs_last_error(NULL): why the last dgs_create on this thread failed
 
 extern "C" {
@@ -168,19 +183,17 @@ void dgs_destroy(dgs_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  h->target.release(); h->source.release();
+  unbind(h, h->tgt_cloud);
+  unbind(h, h->src_cloud);
+  h->own_target.release(); h->own_source.release();
   h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
   h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
-  h->target_bvh.sorted.release(); h->target_bvh.node_lo.release(); h->target_bvh.node_hi.release();
-  h->target_bvh.keys.release(); h->target_bvh.keys_alt.release(); h->target_bvh.vals.release(); h->target_bvh.vals_alt.release();
   h->nn_partials.release(); h->scratch_cloud.release();
-  h->source_bvh.sorted.release(); h->source_bvh.node_lo.release(); h->source_bvh.node_hi.release();
-  h->source_bvh.keys.release(); h->source_bvh.keys_alt.release(); h->source_bvh.vals.release(); h->source_bvh.vals_alt.release();
   h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_out.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
   h->aux_bvh.keys.release(); h->aux_bvh.keys_alt.release(); h->aux_bvh.vals.release(); h->aux_bvh.vals_alt.release();
-  h->cov_target.release(); h->cov_source.release(); h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
+  h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
   for (auto& ep : h->prof.pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -218,10 +231,12 @@ int dgs_set_input_target(dgs_handle* h, const float* xyz16, int64_t n, int32_t o
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_target = false;
-  h->target_bvh.valid = false;
-  h->cov_target_valid = false;
+  unbind(h, h->tgt_cloud);
+  h->tgt = &h->own_target;
+  h->tgt->invalidate();
+  h->tgt->n = n;
   h->nt = n;
-  int rc = upload_cloud(h, h->target, xyz16, n, on_device);
+  int rc = upload_cloud(h, h->own_target.pts, xyz16, n, on_device);
   if (rc) return rc;
   if (h->prm.method == DGS_METHOD_NDT) {
     rc = ndt_build_target(h);
@@ -236,11 +251,77 @@ int dgs_set_input_source(dgs_handle* h, const float* xyz16, int64_t n, int32_t o
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_source = false;
-  h->source_bvh.valid = false;
-  h->cov_source_valid = false;
+  unbind(h, h->src_cloud);
+  h->src = &h->own_source;
+  h->src->invalidate();
+  h->src->n = n;
   h->ns = n;
-  int rc = upload_cloud(h, h->source, xyz16, n, on_device);
+  int rc = upload_cloud(h, h->own_source.pts, xyz16, n, on_device);
   if (rc) return rc;
+  h->have_source = true;
+  return DGS_OK;
+}
+
+// ---- device-resident cloud objects (keyframe cache) ---------------------------------------------------
+int dgs_cloud_create(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_device, dgs_cloud** out) {
+  if (!h || !out || n < 0 || (n > 0 && !xyz16) || n > INT32_MAX) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  *out = nullptr;
+  if (set_device(h)) return DGS_ERR_HIP;
+  dgs_cloud* c = new (std::nothrow) dgs_cloud();
+  if (!c) return DGS_ERR_HIP;
+  c->device = h->device;
+  c->st.n = n;
+  int rc = upload_cloud(h, c->st.pts, xyz16, n, on_device);
+  if (rc == DGS_OK && on_device) {  // the caller may free its buffer as soon as this returns
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; }
+  }
+  if (rc != DGS_OK) {
+    c->st.release();
+    delete c;
+    return rc;
+  }
+  *out = c;
+  return DGS_OK;
+}
+
+void dgs_cloud_destroy(dgs_cloud* c) {
+  if (!c) return;
+  for (dgs_handle* h : c->users) {  // handles still pointing here fall back to "no input set"
+    if (h->tgt_cloud == c) { h->tgt_cloud = nullptr; h->tgt = &h->own_target; h->nt = 0; h->have_target = false; }
+    if (h->src_cloud == c) { h->src_cloud = nullptr; h->src = &h->own_source; h->ns = 0; h->have_source = false; }
+  }
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  c->st.release();
+  delete c;
+}
+
+int64_t dgs_cloud_size(const dgs_cloud* c) { return c ? c->st.n : 0; }
+
+int dgs_set_input_target_cloud(dgs_handle* h, dgs_cloud* c) {
+  if (!h || !c || c->device != h->device) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  h->have_target = false;
+  bind(h, h->tgt_cloud, c);
+  h->tgt = &c->st;
+  h->nt = c->st.n;
+  if (h->prm.method == DGS_METHOD_NDT) {
+    int rc = ndt_build_target(h);
+    if (rc) return rc;
+  }
+  h->have_target = true;
+  return DGS_OK;
+}
+
+int dgs_set_input_source_cloud(dgs_handle* h, dgs_cloud* c) {
+  if (!h || !c || c->device != h->device) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  bind(h, h->src_cloud, c);
+  h->src = &c->st;
+  h->ns = c->st.n;
   h->have_source = true;
   return DGS_OK;
 }
@@ -265,7 +346,7 @@ int dgs_align(dgs_handle* h, const float* guess16, dgs_result* out, float* align
   if (!h->have_source || h->ns == 0) { out->status = DGS_ERR_NO_SOURCE; h->err = "no input source dataset was given"; return DGS_ERR_NO_SOURCE; }
   int rc;
   if (h->prm.method == DGS_METHOD_NDT) {
-    const float4* src = h->source.ptr;
+    const float4* src = h->src->pts.ptr;
     const int n = (int)h->ns;
     rc = ndt_align_pairs(h, 1, &src, &n, guess16, out);
   } else {
@@ -283,7 +364,7 @@ int dgs_align(dgs_handle* h, const float* guess16, dgs_result* out, float* align
       DGS_HIP_TRY(h, h->scratch_cloud.reserve((size_t)h->ns));
       dst = h->scratch_cloud.ptr;
     }
-    transform_cloud(h, h->source.ptr, dst, h->ns, h->final_T);
+    transform_cloud(h, h->src->pts.ptr, dst, h->ns, h->final_T);
     if (!aligned_on_device) {
       DGS_HIP_TRY(h, hipMemcpyAsync(aligned, dst, (size_t)h->ns * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
       DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -300,7 +381,7 @@ int dgs_get_fitness_score(dgs_handle* h, double max_range, double* score) {
   if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
   double sum = 0;
   int64_t cnt = 0, inl = 0;
-  int rc = nn_fitness(h, h->source.ptr, h->ns, h->final_T, max_range, 0.0, &sum, &cnt, &inl);
+  int rc = nn_fitness(h, h->src->pts.ptr, h->ns, h->final_T, max_range, 0.0, &sum, &cnt, &inl);
   if (rc) return rc;
   *score = cnt > 0 ? sum / (double)cnt : DBL_MAX;
   return DGS_OK;
@@ -314,7 +395,7 @@ int dgs_get_inlier_fraction(dgs_handle* h, double max_sq_dist, double* fraction)
   if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
   double sum = 0;
   int64_t cnt = 0, inl = 0;
-  int rc = nn_fitness(h, h->source.ptr, h->ns, h->final_T, DBL_MAX, max_sq_dist, &sum, &cnt, &inl);
+  int rc = nn_fitness(h, h->src->pts.ptr, h->ns, h->final_T, DBL_MAX, max_sq_dist, &sum, &cnt, &inl);
   if (rc) return rc;
   *fraction = (double)inl / (double)h->ns;
   return DGS_OK;
@@ -414,6 +495,34 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
   (void)hipStreamSynchronize(h->stream);
   slab.release();
   return rc;
+}
+
+int dgs_align_batch_clouds(dgs_handle* h, int32_t n, dgs_cloud* const* sources, const float* guesses16, int32_t compute_fitness,
+                           double fitness_max_range, dgs_result* results) {
+  if (!h || n < 0 || (n > 0 && (!sources || !results))) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (n == 0) return DGS_OK;
+  for (int i = 0; i < n; i++)
+    if (!sources[i] || sources[i]->device != h->device) return DGS_ERR_INVALID_ARGUMENT;
+  if (h->prm.method == DGS_METHOD_NDT) {
+    // the batched NDT path already takes device pointers: hand it the resident clouds, nothing is copied
+    std::vector<const float*> ptrs(n);
+    std::vector<int64_t> sizes(n);
+    for (int i = 0; i < n; i++) { ptrs[i] = reinterpret_cast<const float*>(sources[i]->st.pts.ptr); sizes[i] = sources[i]->st.n; }
+    return dgs_align_batch(h, n, ptrs.data(), sizes.data(), 1, guesses16, compute_fitness, fitness_max_range, results);
+  }
+  // FAST_GICP: candidates run one after another, but each resident cloud keeps its index and covariances across calls
+  int rc_all = DGS_OK;
+  for (int i = 0; i < n; i++) {
+    fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_OK);
+    if (sources[i]->st.n <= 0) { results[i].status = DGS_ERR_NO_SOURCE; continue; }
+    int rc = dgs_set_input_source_cloud(h, sources[i]);
+    if (rc == DGS_OK) rc = dgs_align(h, guesses16 ? guesses16 + 16 * i : nullptr, &results[i], nullptr, 0);
+    if (rc == DGS_OK && compute_fitness) rc = dgs_get_fitness_score(h, fitness_max_range, &results[i].fitness);
+    if (rc != DGS_OK) { results[i].status = rc; rc_all = rc; }
+  }
+  return (rc_all == DGS_ERR_HIP) ? rc_all : DGS_OK;
 }
 
 int dgs_profile_enable(dgs_handle* h, int32_t enable) {

@@ -480,32 +480,34 @@ static void fill_gconsts(dgs_handle* h) {
   c.regularization = p.gicp_regularization;
 }
 
-static int ensure_covariance(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n, DevBuf<double>& cov, bool& valid) {
-  if (valid) return DGS_OK;
+static int ensure_covariance(dgs_handle* h, CloudState& c) {
+  if (c.cov_valid && c.cov_k == h->gconsts.k && c.cov_reg == h->gconsts.regularization) return DGS_OK;
   if (h->gconsts.k > kKnnMax) {
     h->err = "reg_correspondence_randomness > 32 is not supported by the HIP k-NN";
     return DGS_ERR_UNSUPPORTED;
   }
-  if (!bvh.valid) {
-    int rc = bvh_build(h, bvh, pts, n);
+  if (!c.bvh.valid) {
+    int rc = bvh_build(h, c.bvh, c.pts.ptr, c.n);
     if (rc) return rc;
   }
-  DGS_HIP_TRY(h, cov.reserve((size_t)n * 6));
-  const BvhView v = make_bvh_view(bvh);
+  DGS_HIP_TRY(h, c.cov.reserve((size_t)c.n * 6));
+  const BvhView v = make_bvh_view(c.bvh);
   int slot = prof_begin(h, DGS_K_GICP_COVARIANCE);
-  hipLaunchKernelGGL(gicp_covariance_kernel, dim3((unsigned)(((int64_t)n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, pts, (int)n, h->gconsts.k,
-                     h->gconsts.regularization, cov.ptr);
+  hipLaunchKernelGGL(gicp_covariance_kernel, dim3((unsigned)(((int64_t)c.n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
+                     h->gconsts.k, h->gconsts.regularization, c.cov.ptr);
   prof_end(h, DGS_K_GICP_COVARIANCE, slot);
   DGS_HIP_TRY(h, hipGetLastError());
-  valid = true;
+  c.cov_valid = true;
+  c.cov_k = h->gconsts.k;
+  c.cov_reg = h->gconsts.regularization;
   return DGS_OK;
 }
 
 static int gicp_prepare(dgs_handle* h) {
   fill_gconsts(h);
-  int rc = ensure_covariance(h, h->source_bvh, h->source.ptr, h->ns, h->cov_source, h->cov_source_valid);
+  int rc = ensure_covariance(h, *h->src);
   if (rc) return rc;
-  rc = ensure_covariance(h, h->target_bvh, h->target.ptr, h->nt, h->cov_target, h->cov_target_valid);
+  rc = ensure_covariance(h, *h->tgt);
   if (rc) return rc;
   DGS_HIP_TRY(h, h->corr.reserve(h->ns));
   DGS_HIP_TRY(h, h->corr_sq.reserve(h->ns));
@@ -519,16 +521,16 @@ static int gicp_prepare(dgs_handle* h) {
 static int gicp_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, 512)); }
 
 static void gicp_launch_round(dgs_handle* h, int nblocks) {
-  const BvhView v = make_bvh_view(h->target_bvh);
+  const BvhView v = make_bvh_view(h->tgt->bvh);
   const int n = (int)h->ns;
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
   const int cblocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)n * 8 + kBlock - 1) / kBlock, 4096));
-  hipLaunchKernelGGL(gicp_correspond_kernel, dim3(cblocks), dim3(kBlock), 0, h->stream, v, h->source_bvh.sorted.ptr, n, h->gpairs.ptr, h->gconsts.max_corr_sq,
+  hipLaunchKernelGGL(gicp_correspond_kernel, dim3(cblocks), dim3(kBlock), 0, h->stream, v, h->src->bvh.sorted.ptr, n, h->gpairs.ptr, h->gconsts.max_corr_sq,
                      h->corr.ptr, h->corr_sq.ptr);
   prof_end(h, DGS_K_NN_SEARCH, slot);
   slot = prof_begin(h, DGS_K_GICP_LINEARIZE);
-  hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblocks), dim3(kBlock), 0, h->stream, h->source.ptr, n, h->target.ptr, h->cov_source.ptr,
-                     h->cov_target.ptr, h->corr.ptr, h->mahal.ptr, h->gpairs.ptr, h->partials.ptr, nblocks);
+  hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblocks), dim3(kBlock), 0, h->stream, h->src->pts.ptr, n, h->tgt->pts.ptr, h->src->cov.ptr,
+                     h->tgt->cov.ptr, h->corr.ptr, h->mahal.ptr, h->gpairs.ptr, h->partials.ptr, nblocks);
   prof_end(h, DGS_K_GICP_LINEARIZE, slot);
   hipLaunchKernelGGL(gicp_solve_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, nblocks, h->gconsts, h->done_counter.ptr);
 }
@@ -610,12 +612,11 @@ int gicp_align(dgs_handle* h, const float* guess16, dgs_result* out) {
 // Test hook: regularised covariances (9 doubles per point, row-major) of the source (which = 0) or target (1) cloud.
 int gicp_covariances(dgs_handle* h, int which, double* host_out9, int64_t n) {
   fill_gconsts(h);
-  int rc = which ? ensure_covariance(h, h->target_bvh, h->target.ptr, h->nt, h->cov_target, h->cov_target_valid)
-                 : ensure_covariance(h, h->source_bvh, h->source.ptr, h->ns, h->cov_source, h->cov_source_valid);
+  int rc = which ? ensure_covariance(h, *h->tgt) : ensure_covariance(h, *h->src);
   if (rc) return rc;
   std::vector<double> c6((size_t)n * 6);
   DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
-  DGS_HIP_TRY(h, hipMemcpy(c6.data(), which ? h->cov_target.ptr : h->cov_source.ptr, c6.size() * sizeof(double), hipMemcpyDeviceToHost));
+  DGS_HIP_TRY(h, hipMemcpy(c6.data(), which ? h->tgt->cov.ptr : h->src->cov.ptr, c6.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (int64_t i = 0; i < n; i++) {
     const double* c = c6.data() + i * 6;
     double* o = host_out9 + i * 9;

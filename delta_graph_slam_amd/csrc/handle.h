@@ -30,7 +30,34 @@ struct Bvh {
   bool valid = false;
 };
 
+// A cloud resident in HBM with everything derived from the points alone: the exact-NN index and (GICP) the regularised
+// k-NN covariances.  Owned by a handle (setInputTarget / setInputSource copies) or by a dgs_cloud object that outlives
+// many registrations (keyframe clouds of the loop detector).
+struct CloudState {
+  DevBuf<float4> pts;
+  int64_t n = 0;
+  Bvh bvh;
+  DevBuf<double> cov;  // 6 doubles per point: xx, xy, xz, yy, yz, zz
+  bool cov_valid = false;
+  int cov_k = 0, cov_reg = -1;
+  void invalidate() { bvh.valid = false; cov_valid = false; }
+  void release() {
+    pts.release(); cov.release();
+    bvh.sorted.release(); bvh.node_lo.release(); bvh.node_hi.release();
+    bvh.keys.release(); bvh.keys_alt.release(); bvh.vals.release(); bvh.vals_alt.release();
+    n = 0;
+    invalidate();
+  }
+};
+
 }  // namespace dgs
+
+struct dgs_handle;
+struct dgs_cloud {
+  dgs::CloudState st;
+  int device = 0;
+  std::vector<dgs_handle*> users;  // handles whose tgt/src point at st: detached again when the cloud is destroyed first
+};
 
 struct dgs_handle {
   dgs_params prm;
@@ -39,8 +66,12 @@ struct dgs_handle {
   bool own_stream = false;
   std::string err;
 
-  // clouds (device copies, pcl::PointXYZ layout)
-  dgs::DevBuf<float4> target, source;
+  // clouds (pcl::PointXYZ layout): the handle's own copies, or borrowed dgs_cloud objects
+  dgs::CloudState own_target, own_source;
+  dgs::CloudState* tgt = &own_target;
+  dgs::CloudState* src = &own_source;
+  dgs_cloud* tgt_cloud = nullptr;  // non-null while tgt / src borrow a dgs_cloud
+  dgs_cloud* src_cloud = nullptr;
   int64_t nt = 0, ns = 0;
   bool have_target = false, have_source = false;
 
@@ -80,8 +111,6 @@ struct dgs_handle {
   float final_T[16];
   bool have_result = false;
 
-  // exact nearest-neighbour index over the target (lazy; rebuilt when the target changes)
-  dgs::Bvh target_bvh;
   dgs::DevBuf<double> nn_partials;
   dgs::DevBuf<float4> scratch_cloud;
 
@@ -91,9 +120,6 @@ struct dgs_handle {
   dgs::Bvh aux_bvh;
 
   // ---- GICP (fast_gicp::FastGICP): k-NN covariances of both clouds, correspondences, Mahalanobis matrices
-  dgs::Bvh source_bvh;
-  dgs::DevBuf<double> cov_target, cov_source;  // 6 doubles per point: xx, xy, xz, yy, yz, zz
-  bool cov_target_valid = false, cov_source_valid = false;
   dgs::DevBuf<int> corr;
   dgs::DevBuf<float> corr_sq;
   dgs::DevBuf<double> mahal;                   // 6 doubles per source point

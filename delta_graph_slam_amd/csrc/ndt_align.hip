@@ -867,7 +867,7 @@ int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len) {
 int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36) {
   hipStream_t st = h->stream;
   NdtLaunch L{};
-  const float4* src = h->source.ptr;
+  const float4* src = h->src->pts.ptr;
   const int n = (int)h->ns;
   float T[16];
   if (T16) {

@@ -293,7 +293,7 @@ int ndt_build_target(dgs_handle* h) {
   float hmm[6];
   int slot = prof_begin(h, DGS_K_NDT_VOXEL_BUILD);
   {
-    const int rc = cloud_minmax(h, h->target.ptr, n, hmm);
+    const int rc = cloud_minmax(h, h->tgt->pts.ptr, n, hmm);
     if (rc != DGS_OK) return rc;
   }
   if (!(hmm[0] <= hmm[3])) {  // no finite point
@@ -350,7 +350,7 @@ int ndt_build_target(dgs_handle* h) {
   DGS_HIP_TRY(h, hipMemsetAsync(h->dev_scalars.ptr, 0, 8 * sizeof(int), st));
   DGS_HIP_TRY(h, hipMemsetAsync(h->run_counts.ptr, 0, (size_t)n * sizeof(int), st));
   const int nb = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, h->target.ptr, n, g, h->key_in.ptr, h->val_in.ptr);
+  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, h->tgt->pts.ptr, n, g, h->key_in.ptr, h->val_in.ptr);
   size_t tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0,
                                                     end_bit, st));
@@ -359,7 +359,7 @@ int ndt_build_target(dgs_handle* h) {
                                                        h->dev_scalars.ptr, (int)n, st));
   tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceScan::ExclusiveSum(h->cub_temp.ptr, tb, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st));
-  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(kBlock), 0, st, h->target.ptr, h->val_out.ptr, n, h->scratch_cloud.ptr);
+  hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(kBlock), 0, st, h->tgt->pts.ptr, h->val_out.ptr, n, h->scratch_cloud.ptr);
 
   // 5. per-voxel statistics
   hipLaunchKernelGGL(voxel_finalize_kernel, dim3(nb), dim3(kBlock), 0, st, h->scratch_cloud.ptr, h->run_keys.ptr, h->run_counts.ptr,

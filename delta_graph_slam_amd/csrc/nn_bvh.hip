@@ -225,14 +225,14 @@ BvhView make_bvh_view(const Bvh& b) {
 }
 
 static int ensure_target_bvh(dgs_handle* h) {
-  if (h->target_bvh.valid) return DGS_OK;
-  return bvh_build(h, h->target_bvh, h->target.ptr, h->nt);
+  if (h->tgt->bvh.valid) return DGS_OK;
+  return bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt);
 }
 
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq) {
   int rc = ensure_target_bvh(h);
   if (rc) return rc;
-  const BvhView v = make_bvh_view(h->target_bvh);
+  const BvhView v = make_bvh_view(h->tgt->bvh);
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
   hipLaunchKernelGGL(nn_search_kernel, dim3((unsigned)((m * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, queries, (int)m, d_idx, d_sq);
   prof_end(h, DGS_K_NN_SEARCH, slot);
@@ -244,7 +244,7 @@ int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
   int rc = ensure_target_bvh(h);
   if (rc) return rc;
-  return nn_fitness_batch_on(h, h->target_bvh, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, max_range, inlier_sq, sums, counts, inliers);
+  return nn_fitness_batch_on(h, h->tgt->bvh, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, max_range, inlier_sq, sums, counts, inliers);
 }
 
 int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,

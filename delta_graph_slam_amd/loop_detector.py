@@ -57,7 +57,8 @@ class Loop:
 
 
 class LoopDetector:
-    def __init__(self, params: Optional[dict] = None, registration=None, group=None, device: Optional[int] = None):
+    def __init__(self, params: Optional[dict] = None, registration=None, group=None, device: Optional[int] = None,
+                 cache_clouds: bool = False):
         pr = dict(params or {})
         self.distance_thresh = float(pr.get("distance_thresh", 5.0))
         self.accum_distance_thresh = float(pr.get("accum_distance_thresh", 8.0))
@@ -71,6 +72,25 @@ class LoopDetector:
         self.last_edge_accum_distance = 0.0
         self.group = group
         self.last_records = None
+        # keyframe id -> DeviceCloud: a keyframe that is a candidate tick after tick (delta_graph_slam_nodelet.cpp:816 calls
+        # detect() every graph_update_interval) is uploaded and indexed once; needs KeyFrame.id to be unique
+        self.cache_clouds = bool(cache_clouds)
+        self._cloud_cache = {}
+
+    def resident(self, keyframe: "KeyFrame"):
+        """KeyFrame::cloud as the registration should see it: the cached HBM-resident object when caching is on."""
+        if not self.cache_clouds or keyframe.id < 0 or not hasattr(self.registration, "make_cloud"):
+            return keyframe.cloud
+        c = self._cloud_cache.get(keyframe.id)
+        if c is None:
+            c = self.registration.make_cloud(keyframe.cloud)
+            self._cloud_cache[keyframe.id] = c
+        return c
+
+    def evict(self, keyframe_id: int):
+        c = self._cloud_cache.pop(keyframe_id, None)
+        if c is not None:
+            c.close()
 
     # ---------------------------------------------------------------------------------------------- reference logic
     def detect(self, keyframes: Sequence[KeyFrame], new_keyframes: Sequence[KeyFrame]) -> List[Loop]:
@@ -113,9 +133,9 @@ class LoopDetector:
         gathered [n_candidates, RECORD_WIDTH] float64 records in original candidate order."""
         rank, world = self._world()
         n = len(candidates)
-        self.registration.setInputTarget(new_keyframe.cloud)
+        self.registration.setInputTarget(self.resident(new_keyframe))
         mine = list(range(rank, n, world))
-        sources = [candidates[c].cloud for c in mine]
+        sources = [self.resident(candidates[c]) for c in mine]
         guesses = [self.guess_for(new_keyframe, candidates[c]) for c in mine]
         results = self.registration.align_batch(sources, guesses, compute_fitness=True,
                                                 fitness_max_range=self.fitness_score_max_range) if mine else []

@@ -24,7 +24,7 @@ try:  # torch is plumbing only: device memory + streams
 except Exception:  # pragma: no cover
     torch = None
 
-__all__ = ["Registration", "select_registration_method", "DgsError"]
+__all__ = ["Registration", "DeviceCloud", "select_registration_method", "DgsError"]
 DgsError = L.DgsError
 
 
@@ -54,6 +54,32 @@ def _col16(T) -> np.ndarray:
 
 def _from_col16(t16) -> np.ndarray:
     return np.array(t16, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class DeviceCloud:
+    """A cloud resident in HBM (dgs_cloud): KeyFrame::cloud of the loop detector kept on the device together with its
+    NN index / GICP covariances, so a keyframe that is a loop candidate tick after tick is uploaded and indexed once."""
+
+    def __init__(self, registration: "Registration", cloud):
+        ptr, n, dev, keep = _cloud_ptr(cloud)
+        self._lib = registration._lib
+        self._c = C.c_void_p()
+        registration._check(self._lib.dgs_cloud_create(registration._h, ptr, n, dev, C.byref(self._c)))
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._lib.dgs_cloud_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Registration:
@@ -109,11 +135,23 @@ class Registration:
         self._check(self._lib.dgs_synchronize(self._h))
 
     # -- pcl::Registration surface ------------------------------------------------------------------------
+    def make_cloud(self, cloud) -> DeviceCloud:
+        return DeviceCloud(self, cloud)
+
     def setInputTarget(self, cloud):
+        if isinstance(cloud, DeviceCloud):
+            self._keep["target"] = cloud
+            self._check(self._lib.dgs_set_input_target_cloud(self._h, cloud._c))
+            return
         ptr, n, dev, keep = _cloud_ptr(cloud)
         self._check(self._lib.dgs_set_input_target(self._h, ptr, n, dev))
 
     def setInputSource(self, cloud):
+        if isinstance(cloud, DeviceCloud):
+            self._keep["source"] = cloud
+            self._n_source = cloud.n
+            self._check(self._lib.dgs_set_input_source_cloud(self._h, cloud._c))
+            return
         ptr, n, dev, keep = _cloud_ptr(cloud)
         self._n_source = n
         self._check(self._lib.dgs_set_input_source(self._h, ptr, n, dev))
@@ -198,6 +236,14 @@ class Registration:
         n = len(sources)
         if n == 0:
             return []
+        if all(isinstance(s_, DeviceCloud) for s_ in sources):
+            cl = (C.c_void_p * n)(*[s_._c.value for s_ in sources])
+            g = None if guesses is None else np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
+            res = (L.Result * n)()
+            self._check(self._lib.dgs_align_batch_clouds(self._h, n, cl, None if g is None else g.ctypes.data_as(C.c_void_p),
+                                                          1 if compute_fitness else 0, fitness_max_range, res))
+            return [dict(T=_from_col16(r.final_transformation), converged=bool(r.converged), iterations=r.iterations,
+                         evaluations=r.evaluations, status=r.status, score=r.score, fitness=r.fitness) for r in res]
         ptrs = (C.c_void_p * n)()
         sizes = (C.c_int64 * n)()
         keep = []

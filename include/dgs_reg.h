@@ -31,6 +31,7 @@ extern "C" {
 #define DGS_ABI_VERSION 1
 
 typedef struct dgs_handle dgs_handle;
+typedef struct dgs_cloud dgs_cloud; /* a cloud resident in HBM together with its NN index / covariances (see below) */
 
 enum dgs_status {
   DGS_OK = 0,
@@ -159,6 +160,22 @@ int dgs_nearest_search_target(dgs_handle* h, const float* queries_xyz16, int64_t
  * (converged, fitness) stays with the caller (loop_detector.hpp:149-155). */
 int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const int64_t* sizes, int32_t on_device,
                     const float* guesses16, int32_t compute_fitness, double fitness_max_range, dgs_result* results);
+
+/* ---- device-resident clouds: KeyFrame::cloud kept in HBM -------------------------------------------------
+ * The loop detector registers the same keyframe clouds again and again (every graph_update_interval tick,
+ * /root/reference/apps/delta_graph_slam_nodelet.cpp:147-148,816; clouds live in KeyFrame::cloud, keyframe.hpp:51).  A dgs_cloud
+ * is uploaded once; the exact-NN index and the GICP covariances derived from it are built on first use and kept, which is
+ * what fast_gicp does per object when setInputSource sees the same pointer again.  A cloud belongs to the device of the
+ * handle that created it, may be used by any handle on that device (one at a time) and must outlive the calls using it. */
+int dgs_cloud_create(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_device, dgs_cloud** out);
+void dgs_cloud_destroy(dgs_cloud* cloud);
+int64_t dgs_cloud_size(const dgs_cloud* cloud);
+/* setInputTarget / setInputSource without a copy */
+int dgs_set_input_target_cloud(dgs_handle* h, dgs_cloud* cloud);
+int dgs_set_input_source_cloud(dgs_handle* h, dgs_cloud* cloud);
+/* dgs_align_batch over resident clouds (loop_detector.hpp:137-156 with cached candidates) */
+int dgs_align_batch_clouds(dgs_handle* h, int32_t n, dgs_cloud* const* sources, const float* guesses16, int32_t compute_fitness,
+                           double fitness_max_range, dgs_result* results);
 
 /* InformationMatrixCalculator::calc_fitness_score(cloud1, cloud2, relpose, max_range)
  * (/root/reference/src/hdl_graph_slam/information_matrix_calculator.cpp:77-108; called per odometry edge and per loop
