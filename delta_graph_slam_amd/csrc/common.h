@@ -102,6 +102,16 @@ struct GicpPair {
   float final_T[16];  // column-major
 };
 
+struct GicpItem {  // one registration of a batch: its source cloud (with index and covariances) and its work arrays
+  const float4* src;         // source points in the caller's order
+  const float4* src_sorted;  // the same points in their own index's Hilbert order, w = original index
+  const double* cov_s;       // 6 doubles per source point
+  int* corr;                 // per source point: index of its target correspondence or -1
+  float* corr_sq;
+  double* mahal;             // 6 doubles per source point
+  int n, pad;
+};
+
 struct GicpConsts {
   double trans_eps, rot_eps, lm_init_lambda_factor;
   float max_corr_sq;  // corr_dist_threshold_^2 as upstream forms it (float)
@@ -119,6 +129,41 @@ struct NdtInit {  // host -> device per pair, per align
   float guess[16];  // column-major
   double p0[6];
 };
+
+// Deals the workgroups of a launch evenly to the pairs of a batch for which pred(pair index) holds (the pairs that still
+// iterate).  Every wave derives the same mapping: one strided load + ballot per 64 pairs, no inter-block traffic.
+// Returns false when this workgroup has nothing to do.  gridDim.x must be >= the number of pairs.
+#ifdef __HIPCC__
+template <class Pred>
+__device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, Pred pred, int& pair, int& slice, int& blocks_per_pair) {
+  const int lane_id = threadIdx.x & 63;
+  int n_active = 0;
+  for (int c0 = 0; c0 < n_pairs; c0 += 64) {
+    const int pi = c0 + lane_id;
+    const bool a = (pi < n_pairs) && pred(pi);
+    n_active += __popcll(__ballot(a));
+  }
+  if (n_active == 0) return false;
+  blocks_per_pair = max(1, min((int)gridDim.x / n_active, cap_blocks));
+  const int rank = blockIdx.x / blocks_per_pair;
+  slice = blockIdx.x % blocks_per_pair;
+  if (rank >= n_active) return false;
+  int found = -1, seen = 0;
+  for (int c0 = 0; c0 < n_pairs && found < 0; c0 += 64) {
+    const int pi = c0 + lane_id;
+    const bool a = (pi < n_pairs) && pred(pi);
+    unsigned long long m = __ballot(a);
+    const int cnt = __popcll(m);
+    if (rank < seen + cnt) {
+      for (int k = rank - seen; k > 0; k--) m &= m - 1ull;  // drop the (rank - seen) lowest set bits
+      found = c0 + __ffsll((long long)m) - 1;
+    }
+    seen += cnt;
+  }
+  pair = __builtin_amdgcn_readfirstlane(found);
+  return true;
+}
+#endif
 
 // ---- error handling --------------------------------------------------------------------------------------
 #define DGS_HIP_TRY(h, expr)                                                                      \

@@ -186,6 +186,8 @@ void dgs_destroy(dgs_handle* h) {
   unbind(h, h->tgt_cloud);
   unbind(h, h->src_cloud);
   h->own_target.release(); h->own_source.release();
+  for (auto& c : h->batch_clouds) c.release();
+  h->gitems.release();
   h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
@@ -429,6 +431,35 @@ int dgs_nearest_search_target(dgs_handle* h, const float* queries, int64_t m, in
   return rc;
 }
 
+// FAST_GICP over a batch of sources (loop_detector.hpp:137-156): batched align, then one fitness launch for all candidates
+static int gicp_batch(dgs_handle* h, int n, CloudState* const* cs, const float* guesses16, int compute_fitness, double fitness_max_range,
+                      dgs_result* results) {
+  int rc = gicp_align_batch(h, n, cs, guesses16, results);
+  if (rc == DGS_OK && compute_fitness) {
+    DGS_HIP_TRY(h, h->src_ptrs.reserve(n));
+    DGS_HIP_TRY(h, h->src_sizes.reserve(n));
+    std::vector<const float4*> ptrs(n);
+    std::vector<int> sz(n);
+    int max_n = 0;
+    for (int i = 0; i < n; i++) { ptrs[i] = cs[i]->pts.ptr; sz[i] = (int)cs[i]->n; max_n = std::max(max_n, sz[i]); }
+    DGS_HIP_TRY(h, hipMemcpyAsync(h->src_ptrs.ptr, ptrs.data(), sizeof(void*) * n, hipMemcpyHostToDevice, h->stream));
+    DGS_HIP_TRY(h, hipMemcpyAsync(h->src_sizes.ptr, sz.data(), sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+    DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));  // ptrs / sz are pageable host memory going out of scope
+    std::vector<double> sums(n);
+    std::vector<int64_t> cnts(n), inl(n);
+    size_t stride = 0;
+    const float* dT = gicp_final_transforms(h, &stride);
+    rc = nn_fitness_batch(h, n, h->src_ptrs.ptr, h->src_sizes.ptr, max_n, dT, stride, fitness_max_range, 0.0, sums.data(), cnts.data(), inl.data());
+    if (rc == DGS_OK)
+      for (int i = 0; i < n; i++) results[i].fitness = cnts[i] > 0 ? sums[i] / (double)cnts[i] : DBL_MAX;
+  }
+  if (rc == DGS_OK) {
+    for (int i = 0; i < n; i++)
+      if (cs[i]->n <= 0) fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_ERR_NO_SOURCE);
+  }
+  return rc;
+}
+
 int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const int64_t* sizes, int32_t on_device, const float* guesses16,
                     int32_t compute_fitness, double fitness_max_range, dgs_result* results) {
   if (!h || n < 0 || (n > 0 && (!sources || !sizes || !results))) return DGS_ERR_INVALID_ARGUMENT;
@@ -442,16 +473,19 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
     return DGS_ERR_NO_TARGET;
   }
   if (h->prm.method != DGS_METHOD_NDT) {
-    // FAST_GICP candidates run one after another on the device (each needs its own source index + covariances)
-    int rc_all = DGS_OK;
+    // FAST_GICP: every candidate needs its own index + covariances; they live in per-slot CloudStates the handle re-uses
+    if (h->batch_clouds.size() < (size_t)n) h->batch_clouds.resize(n);
+    std::vector<CloudState*> cs(n);
     for (int i = 0; i < n; i++) {
-      if (sizes[i] <= 0 || !sources[i]) { fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_ERR_NO_SOURCE); continue; }
-      int rc = dgs_set_input_source(h, sources[i], sizes[i], on_device);
-      if (rc == DGS_OK) rc = dgs_align(h, guesses16 ? guesses16 + 16 * i : nullptr, &results[i], nullptr, 0);
-      if (rc == DGS_OK && compute_fitness) rc = dgs_get_fitness_score(h, fitness_max_range, &results[i].fitness);
-      if (rc != DGS_OK) { results[i].status = rc; rc_all = rc; }
+      if (sizes[i] < 0 || sizes[i] > INT32_MAX) return DGS_ERR_INVALID_ARGUMENT;
+      CloudState& c = h->batch_clouds[i];
+      c.invalidate();
+      c.n = sources[i] ? sizes[i] : 0;
+      int rc = upload_cloud(h, c.pts, sources[i], c.n, on_device);
+      if (rc) return rc;
+      cs[i] = &c;
     }
-    return (rc_all == DGS_ERR_HIP) ? rc_all : DGS_OK;
+    return gicp_batch(h, n, cs.data(), guesses16, compute_fitness, fitness_max_range, results);
   }
   // stage sources on the device when they come from the host (one contiguous slab)
   std::vector<const float4*> ptrs(n);
@@ -512,17 +546,16 @@ int dgs_align_batch_clouds(dgs_handle* h, int32_t n, dgs_cloud* const* sources, 
     for (int i = 0; i < n; i++) { ptrs[i] = reinterpret_cast<const float*>(sources[i]->st.pts.ptr); sizes[i] = sources[i]->st.n; }
     return dgs_align_batch(h, n, ptrs.data(), sizes.data(), 1, guesses16, compute_fitness, fitness_max_range, results);
   }
-  // FAST_GICP: candidates run one after another, but each resident cloud keeps its index and covariances across calls
-  int rc_all = DGS_OK;
-  for (int i = 0; i < n; i++) {
-    fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_OK);
-    if (sources[i]->st.n <= 0) { results[i].status = DGS_ERR_NO_SOURCE; continue; }
-    int rc = dgs_set_input_source_cloud(h, sources[i]);
-    if (rc == DGS_OK) rc = dgs_align(h, guesses16 ? guesses16 + 16 * i : nullptr, &results[i], nullptr, 0);
-    if (rc == DGS_OK && compute_fitness) rc = dgs_get_fitness_score(h, fitness_max_range, &results[i].fitness);
-    if (rc != DGS_OK) { results[i].status = rc; rc_all = rc; }
+  // FAST_GICP: one batched LM loop; each resident cloud keeps its index and covariances across calls
+  for (int i = 0; i < n; i++) fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_OK);
+  if (!h->have_target || h->nt == 0) {
+    for (int i = 0; i < n; i++) results[i].status = DGS_ERR_NO_TARGET;
+    h->err = "no input target dataset was given";
+    return DGS_ERR_NO_TARGET;
   }
-  return (rc_all == DGS_ERR_HIP) ? rc_all : DGS_OK;
+  std::vector<CloudState*> cs(n);
+  for (int i = 0; i < n; i++) cs[i] = &sources[i]->st;
+  return gicp_batch(h, n, cs.data(), guesses16, compute_fitness, fitness_max_range, results);
 }
 
 int dgs_profile_enable(dgs_handle* h, int32_t enable) {

@@ -15,7 +15,9 @@
 //     and queues the next evaluation in place: no host round trip per iteration.
 #include <cfloat>
 #include <cmath>
+#include <cstddef>
 #include <cstring>
+#include <vector>
 
 #include "handle.h"
 #include "nn_group.h"
@@ -106,21 +108,25 @@ __global__ __launch_bounds__(kBlock) void gicp_covariance_kernel(const BvhView b
 // ================================================================================================ K5 correspondences
 // FastGICP::update_correspondences, search part: x' = float(T) * p in float, exact 1-NN in the target, accepted iff
 // d^2 < corr_dist_threshold^2
-__global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b, const float4* __restrict__ src_sorted, int n,
-                                                                 const GicpPair* __restrict__ pairs, float max_sq, int* __restrict__ corr,
-                                                                 float* __restrict__ corr_sq) {
-  const GicpPair& st = pairs[0];
-  if (!st.active || st.eval_kind != 0) return;
+__global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b, const GicpItem* __restrict__ items,
+                                                                 const GicpPair* __restrict__ pairs, const int n_pairs, const int cap_blocks,
+                                                                 const float max_sq) {
+  // workgroups go to the pairs whose queued evaluation is a linearisation (an LM trial re-uses the stored correspondences)
+  int pair, slice, bpp;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0 && pairs[pi].eval_kind == 0; }, pair, slice, bpp)) return;
+  const GicpPair& st = pairs[pair];
+  const GicpItem it = items[pair];
+  const int n = it.n;
   float T[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = (float)st.Teval[k];
   const int sub = threadIdx.x & 7;
   constexpr int QPB = kBlock / 8;
-  const int sweeps = (n + gridDim.x * QPB - 1) / (gridDim.x * QPB);
+  const int sweeps = (n + bpp * QPB - 1) / (bpp * QPB);
   for (int sw = 0; sw < sweeps; sw++) {
     // source points in THEIR index's (Hilbert) order, w = original index: neighbouring groups query neighbouring places
-    const int pos = (sw * gridDim.x + blockIdx.x) * QPB + (threadIdx.x >> 3);
-    const float4 p = (pos < n) ? src_sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pos = (sw * bpp + slice) * QPB + (threadIdx.x >> 3);
+    const float4 p = (pos < n) ? it.src_sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int i = (pos < n) ? (int)__float_as_uint(p.w) : -1;
     const bool alive = pos < n && i >= 0 && i < n;
     const float x = affine_row_rn(T[0], T[1], T[2], T[3], p.x, p.y, p.z);
@@ -131,20 +137,27 @@ __global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b
     nn_query_group(b, x, y, z, alive, max_sq, best, bi);  // nothing farther than the threshold can be a correspondence
     if (alive && sub == 0) {
       const bool ok = (bi != 0x7FFFFFFF) && (best < max_sq);
-      corr[i] = ok ? bi : -1;
-      corr_sq[i] = best;
+      it.corr[i] = ok ? bi : -1;
+      it.corr_sq[i] = best;
     }
   }
 }
 
 // ================================================================================================ K6 linearize / error
-__global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const float4* __restrict__ src, int n, const float4* __restrict__ tgt,
-                                                                const double* __restrict__ cov_s, const double* __restrict__ cov_t,
-                                                                const int* __restrict__ corr, double* __restrict__ mahal,
-                                                                const GicpPair* __restrict__ pairs, double* __restrict__ partials,
-                                                                const int nblocks) {
-  const GicpPair& st = pairs[0];
-  if (!st.active) return;
+__global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const GicpItem* __restrict__ items, const float4* __restrict__ tgt,
+                                                                const double* __restrict__ cov_t, const GicpPair* __restrict__ pairs,
+                                                                double* __restrict__ partials, const int n_pairs, const int cap_blocks,
+                                                                int* __restrict__ pair_blocks) {
+  int pair, slice, nblocks;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, nblocks)) return;
+  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = nblocks;
+  const GicpPair& st = pairs[pair];
+  const GicpItem it = items[pair];
+  const int n = it.n;
+  const float4* __restrict__ src = it.src;
+  const double* __restrict__ cov_s = it.cov_s;
+  const int* __restrict__ corr = it.corr;
+  double* __restrict__ mahal = it.mahal;
   const bool full = st.eval_kind == 0;
   double T[12];
 #pragma unroll
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const float4* __
 #pragma unroll
   for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
 
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += nblocks * kBlock) {
+  for (int i = slice * kBlock + threadIdx.x; i < n; i += nblocks * kBlock) {
     const int j = corr[i];
     if (j < 0) continue;
     const float4 pa = src[i], pb = tgt[j];
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const float4* __
   if (threadIdx.x < kAccumPad) {
     double v = 0.0;
     if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    partials[(size_t)blockIdx.x * kAccumPad + threadIdx.x] = v;
+    partials[((size_t)pair * cap_blocks + slice) * kAccumPad + threadIdx.x] = v;
   }
 }
 
@@ -384,10 +397,13 @@ __device__ void gicp_advance(GicpPair* st, GicpSolver& s, const GicpConsts& c, b
   }
 }
 
-__global__ __launch_bounds__(kBlock) void gicp_solve_kernel(GicpPair* __restrict__ pairs, const double* __restrict__ partials, const int nblocks,
-                                                            const GicpConsts c, int* __restrict__ done_counter) {
-  GicpPair* st = pairs;
+__global__ __launch_bounds__(kBlock) void gicp_solve_kernel(GicpPair* __restrict__ pairs, const double* __restrict__ all_partials,
+                                                            const int* __restrict__ pair_blocks, const int cap_blocks, const GicpConsts c,
+                                                            int* __restrict__ done_counter) {
+  GicpPair* st = pairs + blockIdx.x;  // one workgroup per registration of the batch
   if (!st->active) return;
+  const int nblocks = pair_blocks[blockIdx.x];
+  const double* __restrict__ partials = all_partials + (size_t)blockIdx.x * cap_blocks * kAccumPad;
   __shared__ double sm[kBlock / kAccumPad][kAccumPad];
   const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
   constexpr int G = kBlock / kAccumPad;
@@ -436,14 +452,16 @@ __global__ __launch_bounds__(kBlock) void gicp_solve_kernel(GicpPair* __restrict
 struct GicpInit {
   double x0[12];
   int probe_kind;  // -1: normal align; 0 / 1: probe a linearisation / an error evaluation
-  int pad;
+  int n;           // source size: an empty source never becomes active (PCL's initCompute refuses it)
 };
 
-__global__ void gicp_init_kernel(GicpPair* __restrict__ pairs, const GicpInit* __restrict__ init) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  GicpPair* st = pairs;
+__global__ void gicp_init_kernel(GicpPair* __restrict__ pairs, const GicpInit* __restrict__ inits, const int n_pairs) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= n_pairs) return;
+  GicpPair* st = pairs + pi;
+  const GicpInit* init = inits + pi;
   GicpSolver s;
-  s.phase = (init->probe_kind >= 0) ? GP_PROBE : GP_LINEARIZE_WAIT;
+  s.phase = (init->n <= 0) ? GP_DONE : (init->probe_kind >= 0) ? GP_PROBE : GP_LINEARIZE_WAIT;
   s.iteration = 0;
   s.evaluations = 0;
   s.converged = 0;
@@ -457,7 +475,7 @@ __global__ void gicp_init_kernel(GicpPair* __restrict__ pairs, const GicpInit* _
   s.nu = 2.0;
   st->s = s;
   st->eval_kind = (init->probe_kind > 0) ? 1 : 0;
-  st->active = 1;
+  st->active = (init->n > 0) ? 1 : 0;
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 4; c++) st->final_T[c * 4 + r] = (float)init->x0[r * 4 + c];
   st->final_T[3] = st->final_T[7] = st->final_T[11] = 0.f;
@@ -503,110 +521,195 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
   return DGS_OK;
 }
 
-static int gicp_prepare(dgs_handle* h) {
+// Launch shape of one batch: per-pair caps (what a lone registration gets) and grids dealt over the active pairs.
+struct GicpLaunch {
+  int n_pairs, cap_c, cap_l, grid_c, grid_l;
+};
+
+static GicpLaunch gicp_choose_launch(int n_pairs, int64_t max_n) {
+  GicpLaunch L;
+  L.n_pairs = n_pairs;
+  L.cap_c = (int)std::max<int64_t>(1, std::min<int64_t>((max_n * 8 + kBlock - 1) / kBlock, 4096));
+  L.cap_l = (int)std::max<int64_t>(1, std::min<int64_t>((max_n + kBlock - 1) / kBlock, 512));
+  L.grid_c = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_c, 8192));
+  L.grid_l = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_l, 2048));
+  return L;
+}
+
+static void gicp_launch_round(dgs_handle* h, const GicpLaunch& L) {
+  const BvhView v = make_bvh_view(h->tgt->bvh);
+  int slot = prof_begin(h, DGS_K_NN_SEARCH);
+  hipLaunchKernelGGL(gicp_correspond_kernel, dim3(L.grid_c), dim3(kBlock), 0, h->stream, v, h->gitems.ptr, h->gpairs.ptr, L.n_pairs, L.cap_c,
+                     h->gconsts.max_corr_sq);
+  prof_end(h, DGS_K_NN_SEARCH, slot);
+  slot = prof_begin(h, DGS_K_GICP_LINEARIZE);
+  hipLaunchKernelGGL(gicp_linearize_kernel, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->tgt->pts.ptr, h->tgt->cov.ptr, h->gpairs.ptr,
+                     h->partials.ptr, L.n_pairs, L.cap_l, h->pair_blocks.ptr);
+  prof_end(h, DGS_K_GICP_LINEARIZE, slot);
+  hipLaunchKernelGGL(gicp_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, h->pair_blocks.ptr, L.cap_l,
+                     h->gconsts, h->done_counter.ptr);
+}
+
+// pinned staging: [0,64) done flags | inits | items | pairs read back
+static size_t gicp_pinned_layout(int n, size_t* off_init, size_t* off_items, size_t* off_pairs) {
+  size_t o = 64;
+  *off_init = o;
+  o += (size_t)n * sizeof(GicpInit);
+  o = (o + 63) & ~(size_t)63;
+  *off_items = o;
+  o += (size_t)n * sizeof(GicpItem);
+  o = (o + 63) & ~(size_t)63;
+  *off_pairs = o;
+  o += (size_t)n * sizeof(GicpPair);
+  return o;
+}
+
+// Covariances and indices of every cloud, work arrays, per-pair state: everything a batch needs before its first round.
+static int gicp_start(dgs_handle* h, int n, CloudState* const* srcs, const double* x0_rows, int probe_kind, GicpLaunch* L_out, int* n_live) {
+  hipStream_t st = h->stream;
   fill_gconsts(h);
-  int rc = ensure_covariance(h, *h->src);
+  int rc = ensure_covariance(h, *h->tgt);
   if (rc) return rc;
-  rc = ensure_covariance(h, *h->tgt);
-  if (rc) return rc;
-  DGS_HIP_TRY(h, h->corr.reserve(h->ns));
-  DGS_HIP_TRY(h, h->corr_sq.reserve(h->ns));
-  DGS_HIP_TRY(h, h->mahal.reserve((size_t)h->ns * 6));
-  DGS_HIP_TRY(h, h->gpairs.reserve(1));
-  DGS_HIP_TRY(h, h->inits.reserve(2));
+  int64_t total = 0, max_n = 1;
+  *n_live = 0;
+  for (int i = 0; i < n; i++) {
+    if (srcs[i]->n <= 0) continue;
+    rc = ensure_covariance(h, *srcs[i]);
+    if (rc) return rc;
+    total += srcs[i]->n;
+    max_n = std::max<int64_t>(max_n, srcs[i]->n);
+    (*n_live)++;
+  }
+  const GicpLaunch L = gicp_choose_launch(n, max_n);
+  *L_out = L;
+  DGS_HIP_TRY(h, h->corr.reserve((size_t)std::max<int64_t>(total, 1)));
+  DGS_HIP_TRY(h, h->corr_sq.reserve((size_t)std::max<int64_t>(total, 1)));
+  DGS_HIP_TRY(h, h->mahal.reserve((size_t)std::max<int64_t>(total, 1) * 6));
+  DGS_HIP_TRY(h, h->gpairs.reserve(n));
+  DGS_HIP_TRY(h, h->gitems.reserve(n));
+  DGS_HIP_TRY(h, h->inits.reserve(n));  // sizeof(NdtInit) >= sizeof(GicpInit)
+  static_assert(sizeof(NdtInit) >= sizeof(GicpInit), "init staging buffer is shared with NDT");
+  DGS_HIP_TRY(h, h->pair_blocks.reserve(n));
   DGS_HIP_TRY(h, h->done_counter.reserve(16));
+  DGS_HIP_TRY(h, h->partials.reserve((size_t)n * L.cap_l * kAccumPad + 64));
+  size_t oi, ot, op;
+  const size_t bytes = gicp_pinned_layout(n, &oi, &ot, &op);
+  if (ensure_pinned(h, bytes) != DGS_OK) return DGS_ERR_HIP;
+  char* base = reinterpret_cast<char*>(h->pinned);
+  GicpInit* hin = reinterpret_cast<GicpInit*>(base + oi);
+  GicpItem* hit = reinterpret_cast<GicpItem*>(base + ot);
+  int64_t off = 0;
+  for (int i = 0; i < n; i++) {
+    const CloudState& c = *srcs[i];
+    for (int k = 0; k < 12; k++) hin[i].x0[k] = x0_rows[12 * i + k];
+    hin[i].probe_kind = probe_kind;
+    hin[i].n = (int)c.n;
+    hit[i].src = c.pts.ptr;
+    hit[i].src_sorted = c.bvh.sorted.ptr;
+    hit[i].cov_s = c.cov.ptr;
+    hit[i].corr = h->corr.ptr + off;
+    hit[i].corr_sq = h->corr_sq.ptr + off;
+    hit[i].mahal = h->mahal.ptr + off * 6;
+    hit[i].n = (int)c.n;
+    hit[i].pad = 0;
+    off += c.n;
+  }
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, hin, (size_t)n * sizeof(GicpInit), hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->gitems.ptr, hit, (size_t)n * sizeof(GicpItem), hipMemcpyHostToDevice, st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->done_counter.ptr, 0, 16 * sizeof(int), st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->pair_blocks.ptr, 0, (size_t)n * sizeof(int), st));
+  hipLaunchKernelGGL(gicp_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, h->gpairs.ptr, reinterpret_cast<const GicpInit*>(h->inits.ptr), n);
   return DGS_OK;
 }
 
-static int gicp_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, 512)); }
-
-static void gicp_launch_round(dgs_handle* h, int nblocks) {
-  const BvhView v = make_bvh_view(h->tgt->bvh);
-  const int n = (int)h->ns;
-  int slot = prof_begin(h, DGS_K_NN_SEARCH);
-  const int cblocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)n * 8 + kBlock - 1) / kBlock, 4096));
-  hipLaunchKernelGGL(gicp_correspond_kernel, dim3(cblocks), dim3(kBlock), 0, h->stream, v, h->src->bvh.sorted.ptr, n, h->gpairs.ptr, h->gconsts.max_corr_sq,
-                     h->corr.ptr, h->corr_sq.ptr);
-  prof_end(h, DGS_K_NN_SEARCH, slot);
-  slot = prof_begin(h, DGS_K_GICP_LINEARIZE);
-  hipLaunchKernelGGL(gicp_linearize_kernel, dim3(nblocks), dim3(kBlock), 0, h->stream, h->src->pts.ptr, n, h->tgt->pts.ptr, h->src->cov.ptr,
-                     h->tgt->cov.ptr, h->corr.ptr, h->mahal.ptr, h->gpairs.ptr, h->partials.ptr, nblocks);
-  prof_end(h, DGS_K_GICP_LINEARIZE, slot);
-  hipLaunchKernelGGL(gicp_solve_kernel, dim3(1), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, nblocks, h->gconsts, h->done_counter.ptr);
+static GicpPair* gicp_read_back(dgs_handle* h, int n, int* rc) {
+  size_t oi, ot, op;
+  (void)gicp_pinned_layout(n, &oi, &ot, &op);
+  GicpPair* hp = reinterpret_cast<GicpPair*>(reinterpret_cast<char*>(h->pinned) + op);
+  *rc = DGS_OK;
+  if (hipMemcpyAsync(hp, h->gpairs.ptr, (size_t)n * sizeof(GicpPair), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+    h->err = "reading the GICP optimiser state back failed";
+    *rc = DGS_ERR_HIP;
+  }
+  return hp;
 }
 
-static int gicp_start(dgs_handle* h, const double* x0_rows, int probe_kind, int* nblocks_out) {
+// FastGICP::align for every source of a batch against the handle's target; the LM loops of all pairs advance together,
+// one (correspond, linearize, solve) launch triple per round, and pairs that finish hand their workgroups to the rest.
+int gicp_align_batch(dgs_handle* h, int n, CloudState* const* srcs, const float* guesses16, dgs_result* out) {
   hipStream_t st = h->stream;
-  int rc = gicp_prepare(h);
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::vector<double> x0((size_t)n * 12);
+  for (int i = 0; i < n; i++) {
+    const float* G = guesses16 ? guesses16 + 16 * i : ident;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 4; c++) x0[(size_t)i * 12 + r * 4 + c] = (double)G[c * 4 + r];  // Eigen::Isometry3d(guess.cast<double>())
+  }
+  GicpLaunch L;
+  int n_live = 0;
+  int rc = gicp_start(h, n, srcs, x0.data(), -1, &L, &n_live);
   if (rc) return rc;
-  const int nblocks = gicp_blocks(h->ns);
-  *nblocks_out = nblocks;
-  DGS_HIP_TRY(h, h->partials.reserve((size_t)nblocks * kAccumPad + 64));
-  if (ensure_pinned(h, 8192 + sizeof(GicpPair)) != DGS_OK) return DGS_ERR_HIP;
-  GicpInit* hin = reinterpret_cast<GicpInit*>(reinterpret_cast<char*>(h->pinned) + 1024);
-  for (int k = 0; k < 12; k++) hin->x0[k] = x0_rows[k];
-  hin->probe_kind = probe_kind;
-  hin->pad = 0;
-  DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, hin, sizeof(GicpInit), hipMemcpyHostToDevice, st));
-  DGS_HIP_TRY(h, hipMemsetAsync(h->done_counter.ptr, 0, 16 * sizeof(int), st));
-  hipLaunchKernelGGL(gicp_init_kernel, dim3(1), dim3(64), 0, st, h->gpairs.ptr, reinterpret_cast<const GicpInit*>(h->inits.ptr));
+
+  if (n_live > 0) {
+    volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);
+    flags[0] = flags[1] = 0;
+    hipEvent_t ev[2];
+    DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    const long max_rounds = (long)h->prm.maximum_iterations * (h->prm.gicp_lm_max_iterations + 1) + 4;
+    const int chunk = 4;
+    long queued = 0;
+    auto enqueue_chunk = [&](int slot) -> int {
+      for (int e = 0; e < chunk; e++) gicp_launch_round(h, L);
+      queued += chunk;
+      DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+      DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
+      return DGS_OK;
+    };
+    int cur = 0;
+    rc = enqueue_chunk(0);
+    while (rc == DGS_OK) {
+      const bool more = queued < max_rounds;
+      if (more) rc = enqueue_chunk(cur ^ 1);
+      if (rc != DGS_OK) break;
+      hipError_t e = hipEventSynchronize(ev[cur]);
+      if (e != hipSuccess) { h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; break; }
+      if (flags[cur] >= n_live) break;
+      if (!more) break;
+      cur ^= 1;
+    }
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    if (rc != DGS_OK) return rc;
+  }
+  GicpPair* hp = gicp_read_back(h, n, &rc);
+  if (rc) return rc;
+  long evals = 0;
+  for (int i = 0; i < n; i++) {
+    std::memcpy(out[i].final_transformation, hp[i].final_T, sizeof(float) * 16);
+    const bool empty = srcs[i]->n <= 0;
+    out[i].converged = (!empty && hp[i].s.phase == GP_DONE) ? hp[i].s.converged : 0;
+    out[i].iterations = hp[i].s.iteration;
+    out[i].evaluations = hp[i].s.evaluations;
+    out[i].status = empty ? DGS_ERR_NO_SOURCE : DGS_OK;
+    out[i].score = hp[i].s.y0;
+    out[i].fitness = NAN;
+    evals += hp[i].s.evaluations;
+  }
+  h->last_evaluations = evals;
   return DGS_OK;
 }
 
 int gicp_align(dgs_handle* h, const float* guess16, dgs_result* out) {
-  hipStream_t st = h->stream;
-  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  const float* G = guess16 ? guess16 : ident;
-  double x0[12];
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 4; c++) x0[r * 4 + c] = (double)G[c * 4 + r];  // Eigen::Isometry3d(guess.cast<double>())
-  int nblocks = 1;
-  int rc = gicp_start(h, x0, -1, &nblocks);
-  if (rc) return rc;
+  CloudState* one[1] = {h->src};
+  return gicp_align_batch(h, 1, one, guess16, out);
+}
 
-  volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);
-  flags[0] = flags[1] = 0;
-  hipEvent_t ev[2];
-  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-  const long max_rounds = (long)h->prm.maximum_iterations * (h->prm.gicp_lm_max_iterations + 1) + 4;
-  const int chunk = 4;
-  long queued = 0;
-  auto enqueue_chunk = [&](int slot) -> int {
-    for (int e = 0; e < chunk; e++) gicp_launch_round(h, nblocks);
-    queued += chunk;
-    DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
-    DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
-    return DGS_OK;
-  };
-  int cur = 0;
-  rc = enqueue_chunk(0);
-  while (rc == DGS_OK) {
-    const bool more = queued < max_rounds;
-    if (more) rc = enqueue_chunk(cur ^ 1);
-    if (rc != DGS_OK) break;
-    hipError_t e = hipEventSynchronize(ev[cur]);
-    if (e != hipSuccess) { h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; break; }
-    if (flags[cur] >= 1) break;
-    if (!more) break;
-    cur ^= 1;
-  }
-  (void)hipEventDestroy(ev[0]);
-  (void)hipEventDestroy(ev[1]);
-  if (rc != DGS_OK) return rc;
-  GicpPair* hp = reinterpret_cast<GicpPair*>(reinterpret_cast<char*>(h->pinned) + 4096);
-  DGS_HIP_TRY(h, hipMemcpyAsync(hp, h->gpairs.ptr, sizeof(GicpPair), hipMemcpyDeviceToHost, st));
-  DGS_HIP_TRY(h, hipStreamSynchronize(st));
-  DGS_HIP_TRY(h, hipGetLastError());
-  std::memcpy(out->final_transformation, hp->final_T, sizeof(float) * 16);
-  out->converged = (hp->s.phase == GP_DONE) ? hp->s.converged : 0;
-  out->iterations = hp->s.iteration;
-  out->evaluations = hp->s.evaluations;
-  out->status = DGS_OK;
-  out->score = hp->s.y0;
-  out->fitness = NAN;
-  h->last_evaluations = hp->s.evaluations;
-  return DGS_OK;
+// device pointer and stride of the batch's final transforms (column-major float[16] per pair) for the fitness kernel
+const float* gicp_final_transforms(dgs_handle* h, size_t* stride_bytes) {
+  *stride_bytes = sizeof(GicpPair);
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->gpairs.ptr) + offsetof(GicpPair, final_T));
 }
 
 // Test hook: regularised covariances (9 doubles per point, row-major) of the source (which = 0) or target (1) cloud.
@@ -627,15 +730,15 @@ int gicp_covariances(dgs_handle* h, int which, double* host_out9, int64_t n) {
 
 // Test hook: one linearize (error_only = 0: fresh correspondences at T) or compute_error (1: stored correspondences).
 int gicp_probe(dgs_handle* h, const double* T16, int error_only, double* err, double* H36, double* b6) {
-  hipStream_t st = h->stream;
-  int nblocks = 1;
-  int rc = gicp_start(h, T16, error_only ? 1 : 0, &nblocks);
+  GicpLaunch L;
+  int n_live = 0;
+  CloudState* one[1] = {h->src};
+  int rc = gicp_start(h, 1, one, T16, error_only ? 1 : 0, &L, &n_live);
   if (rc) return rc;
-  gicp_launch_round(h, nblocks);
-  GicpPair* hp = reinterpret_cast<GicpPair*>(reinterpret_cast<char*>(h->pinned) + 4096);
-  DGS_HIP_TRY(h, hipMemcpyAsync(hp, h->gpairs.ptr, sizeof(GicpPair), hipMemcpyDeviceToHost, st));
-  DGS_HIP_TRY(h, hipStreamSynchronize(st));
-  DGS_HIP_TRY(h, hipGetLastError());
+  if (n_live == 0) return DGS_ERR_NO_SOURCE;
+  gicp_launch_round(h, L);
+  GicpPair* hp = gicp_read_back(h, 1, &rc);
+  if (rc) return rc;
   *err = error_only ? hp->s.yi : hp->s.y0;
   if (!error_only) {
     for (int k = 0; k < 36; k++) H36[k] = hp->s.H[k];

@@ -124,6 +124,8 @@ struct dgs_handle {
   dgs::DevBuf<float> corr_sq;
   dgs::DevBuf<double> mahal;                   // 6 doubles per source point
   dgs::DevBuf<dgs::GicpPair> gpairs;
+  dgs::DevBuf<dgs::GicpItem> gitems;
+  std::vector<dgs::CloudState> batch_clouds;   // index + covariances of sources handed to dgs_align_batch as raw arrays
   dgs::GicpConsts gconsts{};
 
   dgs::Profiler prof;
@@ -158,6 +160,8 @@ int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const floa
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
 // gicp.hip
 int gicp_align(dgs_handle* h, const float* guess16, dgs_result* out);
+int gicp_align_batch(dgs_handle* h, int n, CloudState* const* srcs, const float* guesses16, dgs_result* out);
+const float* gicp_final_transforms(dgs_handle* h, size_t* stride_bytes);
 int gicp_covariances(dgs_handle* h, int which, double* host_out6, int64_t n);
 int gicp_probe(dgs_handle* h, const double* T16_rowmajor, int error_only, double* err, double* H36, double* b6);
 // transform

@@ -96,7 +96,7 @@ def test_align_with_guess_vlp16_frames(oracle_lib):
     assert dt < 0.3 and dr < 2e-2      # sanity only: a street canyon seen by 16 beams constrains x weakly at eps 0.1
 
 
-def test_batch_is_sequential_singles(oracle_lib):
+def test_batch_matches_oracle_singles(oracle_lib):
     tgt, src, _ = synth.planar_pair(n=4096)
     o, r = _pair(oracle_lib, tgt, src)
     sources = [src[:3000].copy(), src.copy(), np.zeros((0, 4), np.float32)]
@@ -110,3 +110,33 @@ def test_batch_is_sequential_singles(oracle_lib):
         assert dt <= TOL_TRANS and dr <= TOL_ROT
         fo, _, _ = oracle_lib.fitness_score(tgt, sources[k], res[k]["T"])
         assert abs(res[k]["fitness"] - fo) <= 1e-12 * fo
+
+
+def test_batch_of_many_pairs_matches_single_aligns():
+    """The batched LM loop (pairs advance together, workgroups re-dealt as pairs finish) against one align per candidate."""
+    from delta_graph_slam_amd.registration import Registration
+    tgt, src, _ = synth.planar_pair(n=8192)
+    rng = np.random.default_rng(5)
+    sources, guesses = [], []
+    for k in range(11):
+        m = int(rng.integers(500, 8192))
+        sources.append(src[rng.permutation(8192)[:m]].copy())
+        guesses.append(synth.make_transform(rng.uniform(-0.15, 0.15, 3), rng.uniform(-0.02, 0.02, 3)).astype(np.float32))
+    sources.insert(4, np.zeros((0, 4), np.float32))
+    guesses.insert(4, np.eye(4, dtype=np.float32))
+    r = Registration("FAST_GICP", gicp_max_correspondence_distance=2.0)
+    r.setInputTarget(tgt)
+    res = r.align_batch(sources, guesses, compute_fitness=True)
+    assert res[4]["status"] == 4 and not res[4]["converged"] and np.array_equal(res[4]["T"], guesses[4])
+    single = Registration("FAST_GICP", gicp_max_correspondence_distance=2.0)
+    single.setInputTarget(tgt)
+    for k, (s_, g) in enumerate(zip(sources, guesses)):
+        if k == 4:
+            continue
+        single.setInputSource(s_)
+        single.align(g)
+        assert res[k]["converged"] == single.hasConverged()
+        assert res[k]["iterations"] == single.last_result.iterations and res[k]["evaluations"] == single.last_result.evaluations
+        dt, dr = pose_error(res[k]["T"], single.getFinalTransformation())
+        assert dt <= 1e-6 and dr <= 1e-7, (k, dt, dr)
+        assert abs(res[k]["fitness"] - single.getFitnessScore()) <= 1e-9 * abs(res[k]["fitness"])
