@@ -122,10 +122,14 @@ __global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b
   for (int k = 0; k < 12; k++) T[k] = (float)st.Teval[k];
   const int sub = threadIdx.x & 7;
   constexpr int QPB = kBlock / 8;
-  const int sweeps = (n + bpp * QPB - 1) / (bpp * QPB);
-  for (int sw = 0; sw < sweeps; sw++) {
-    // source points in THEIR index's (Hilbert) order, w = original index: neighbouring groups query neighbouring places
-    const int pos = (sw * bpp + slice) * QPB + (threadIdx.x >> 3);
+  // every wave walks a contiguous stretch of the source in ITS index's (Hilbert) order (w = original index), 8 adjacent
+  // points per round: the previous round's correspondences bound this round's searches (nn_warm_bound_round)
+  const int run = (n + bpp * QPB - 1) / (bpp * QPB);
+  const int first = (slice * (kBlock / kWave) + (threadIdx.x >> 6)) * (8 * run) + ((threadIdx.x & 63) >> 3);
+  float px = 0.f, py = 0.f, pz = 0.f, prev_best = INFINITY;
+  bool prev_found = false;
+  for (int r = 0; r < run; r++) {
+    const int pos = first + r * 8;
     const float4 p = (pos < n) ? it.src_sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int i = (pos < n) ? (int)__float_as_uint(p.w) : -1;
     const bool alive = pos < n && i >= 0 && i < n;
@@ -134,11 +138,16 @@ __global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b
     const float z = affine_row_rn(T[8], T[9], T[10], T[11], p.x, p.y, p.z);
     float best;
     int bi;
-    nn_query_group(b, x, y, z, alive, max_sq, best, bi);  // nothing farther than the threshold can be a correspondence
+    // nothing farther than the threshold can be a correspondence
+    const float bound = fminf(max_sq, nn_warm_bound_round(prev_best, prev_found, x, y, z, px, py, pz));
+    nn_query_group(b, x, y, z, alive, bound, best, bi);
+    prev_found = alive && bi != 0x7FFFFFFF;
+    prev_best = best;
+    px = x; py = y; pz = z;
     if (alive && sub == 0) {
       const bool ok = (bi != 0x7FFFFFFF) && (best < max_sq);
       it.corr[i] = ok ? bi : -1;
-      it.corr_sq[i] = best;
+      it.corr_sq[i] = (bi != 0x7FFFFFFF) ? best : max_sq;
     }
   }
 }

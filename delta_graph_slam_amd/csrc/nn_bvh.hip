@@ -92,17 +92,27 @@ __global__ __launch_bounds__(kBlock) void bvh_boxes_kernel(const float4* __restr
   box_hi[parent * kFan + slot] = make_float4(mx[0], mx[1], mx[2], 0.f);
 }
 
+
 __global__ __launch_bounds__(kBlock) void nn_search_kernel(const BvhView b, const float4* __restrict__ q, int m, int* __restrict__ idx,
-                                                           float* __restrict__ sq) {
-  const int qi = (blockIdx.x * kBlock + threadIdx.x) >> 3;  // one query per 8 lanes
-  const bool alive = qi < m;
-  const float4 p = alive ? q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
-  float best;
-  int bi;
-  nn_query_group(b, p.x, p.y, p.z, alive, INFINITY, best, bi);
-  if (alive && (threadIdx.x & 7) == 0) {
-    idx[qi] = bi;
-    sq[qi] = best;
+                                                           float* __restrict__ sq, const int rounds) {
+  // a wave takes 64 * rounds consecutive queries, 8 adjacent ones per round; each round's results bound the next round's searches
+  const int first = ((blockIdx.x * kBlock + threadIdx.x) >> 6) * (8 * rounds) + ((threadIdx.x & 63) >> 3);
+  float px = 0.f, py = 0.f, pz = 0.f, prev_best = INFINITY;
+  bool prev_found = false;
+  for (int r = 0; r < rounds; r++) {
+    const int qi = first + r * 8;
+    const bool alive = qi < m;
+    const float4 p = alive ? q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float best;
+    int bi;
+    nn_query_group(b, p.x, p.y, p.z, alive, nn_warm_bound_round(prev_best, prev_found, p.x, p.y, p.z, px, py, pz), best, bi);
+    prev_found = alive && bi != 0x7FFFFFFF;
+    prev_best = best;
+    px = p.x; py = p.y; pz = p.z;
+    if (alive && (threadIdx.x & 7) == 0) {
+      idx[qi] = bi;
+      sq[qi] = (bi != 0x7FFFFFFF) ? best : INFINITY;
+    }
   }
 }
 
@@ -119,9 +129,15 @@ __global__ __launch_bounds__(kBlock) void nn_fitness_kernel(const BvhView b, con
   double s = 0.0, c = 0.0, inl = 0.0;
   constexpr int QPB = kBlock / 8;  // queries per block per sweep
   const int sub = threadIdx.x & 7;
-  const int sweeps = (n + blocks_per_pair * QPB - 1) / (blocks_per_pair * QPB);
-  for (int sw = 0; sw < sweeps; sw++) {
-    const int i = (sw * blocks_per_pair + blockIdx.x) * QPB + (threadIdx.x >> 3);
+  // every wave walks a contiguous stretch of the source, 8 adjacent points per round: consecutive points of a scan are
+  // neighbours, so the previous round's results bound this round's searches (nn_warm_bound_round) and most of the tree is
+  // pruned before it is touched
+  const int run = (n + blocks_per_pair * QPB - 1) / (blocks_per_pair * QPB);
+  const int first = (blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * (8 * run) + ((threadIdx.x & 63) >> 3);
+  float px = 0.f, py = 0.f, pz = 0.f, prev_best = INFINITY;
+  bool prev_found = false;
+  for (int r = 0; r < run; r++) {
+    const int i = first + r * 8;
     const bool alive = i < n;
     const float4 p = alive ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     // pcl::transformPointCloud: ((m0 x + m1 y) + m2 z) + m3 in float, every step rounded
@@ -130,8 +146,12 @@ __global__ __launch_bounds__(kBlock) void nn_fitness_kernel(const BvhView b, con
     const float z = affine_row_rn(t20, t21, t22, t23, p.x, p.y, p.z);
     float best;
     int bi;
-    nn_query_group(b, x, y, z, alive, INFINITY, best, bi);
+    nn_query_group(b, x, y, z, alive, nn_warm_bound_round(prev_best, prev_found, x, y, z, px, py, pz), best, bi);
+    prev_found = alive && bi != 0x7FFFFFFF;
+    prev_best = best;
+    px = x; py = y; pz = z;
     if (alive && sub == 0) {
+      if (bi == 0x7FFFFFFF) best = INFINITY;  // nothing found (empty index / non-finite query): as the unbounded search reports it
       if (best <= max_range) {  // PCL compares the SQUARED distance with max_range
         s += (double)best;
         c += 1.0;
@@ -234,7 +254,10 @@ int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, f
   if (rc) return rc;
   const BvhView v = make_bvh_view(h->tgt->bvh);
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
-  hipLaunchKernelGGL(nn_search_kernel, dim3((unsigned)((m * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, queries, (int)m, d_idx, d_sq);
+  // one round while the queries alone fill the chip (8192 resident waves of 8 queries), more rounds -- and their warm bounds -- beyond that
+  const int rounds = (int)std::max<int64_t>(1, std::min<int64_t>(m / 65536, 8));
+  const int64_t waves = (m + 8 * rounds - 1) / (8 * rounds);
+  hipLaunchKernelGGL(nn_search_kernel, dim3((unsigned)((waves * kWave + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, queries, (int)m, d_idx, d_sq, rounds);
   prof_end(h, DGS_K_NN_SEARCH, slot);
   DGS_HIP_TRY(h, hipGetLastError());
   return DGS_OK;

@@ -83,6 +83,41 @@ __device__ __forceinline__ float group8_min_f32(float v) {
   return v;
 }
 
+// heap index of the first node of a level of the implicit 8-ary tree: (8^l - 1) / 7
+__device__ __forceinline__ int heap_first(int level) { return (int)(((1u << (3 * level)) - 1u) / 7u); }
+
+// Leaves `node` (at `level`) for the deepest shallower level that still has pending children; levels whose pending byte is
+// empty are skipped without touching their boxes.  Returns false when nothing is pending anywhere (the query is finished).
+__device__ __forceinline__ bool nn_pop(const unsigned long long pend, int& node, int& level) {
+  const unsigned long long pm = pend & ((1ull << (8 * level)) - 1ull);
+  if (pm == 0ull) return false;
+  const int up = (63 - __clzll((long long)pm)) >> 3;
+  node = heap_first(up) + ((node - heap_first(level)) >> (3 * (level - up)));
+  level = up;
+  return true;
+}
+
+// Upper bound on the squared NN distance of q given the previous query q' of the same group and its squared NN distance:
+// |q - NN(q')| <= |q' - NN(q')| + |q - q'| (triangle inequality), inflated against rounding.  Pruning only: the result
+// of the bounded search is the exact NN (and the same index on ties) as the unbounded one.
+__device__ __forceinline__ float nn_warm_bound(float prev_best, bool prev_found, float x, float y, float z, float px, float py, float pz) {
+  if (!prev_found) return INFINITY;
+  const float step = sqrtf(sqdist_rn(x, y, z, px, py, pz));
+  const float r = (sqrtf(prev_best) + step) * 1.0001f + 1e-30f;
+  const float b2 = r * r;
+  return (b2 == b2) ? b2 : INFINITY;
+}
+
+// The 8 groups of a wave search 8 ADJACENT queries at a time (they then walk the same nodes together: no divergence, one
+// L1 line serves all) and take the next 8 in the next round.  Bound for this group's query from the 8 results of the wave's
+// previous round: lane (group, sub) looks at the previous query of group `sub`, the group keeps the tightest bound.
+__device__ __forceinline__ float nn_warm_bound_round(float prev_best, bool prev_found, float x, float y, float z, float px, float py, float pz) {
+  const int from = (threadIdx.x & 7) << 3;  // any lane of group `sub` holds that group's previous query
+  const float ob = __shfl(prev_best, from), ox = __shfl(px, from), oy = __shfl(py, from), oz = __shfl(pz, from);
+  const int of = __shfl(prev_found ? 1 : 0, from);
+  return group8_min_f32(nn_warm_bound(ob, of != 0, x, y, z, ox, oy, oz));
+}
+
 // Exact 1-NN of (x, y, z) for the 8-lane group this lane belongs to; x, y, z must be equal across the group.
 // (Measured and rejected: keeping the child-box distances of every level in registers to skip the reload on the way
 // back up costs more select instructions than the L1-resident reload saves; the traversal is VALU-issue bound.)
@@ -98,7 +133,7 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
   bool fresh = true;
   bool done = !alive;
 #ifdef DGS_NN_STEPS
-  int n_nodes = 0, n_leaves = 0;
+  int n_nodes = 0, n_leaves = 0, n_wasted = 0;
 #endif
   while (__any(!done)) {
     if (!done) {
@@ -110,6 +145,9 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
       // empty slots carry inverted boxes (distance +inf): never enter them, even while best is still +inf
       unsigned mask = (unsigned)((__ballot(d <= best && d < INFINITY) >> gshift) & 0xFFull);
       if (!fresh) mask &= (unsigned)((pend >> (8 * level)) & 0xFFull);
+#ifdef DGS_NN_STEPS
+      if (!fresh && mask == 0) n_wasted++;
+#endif
       const bool last = (level + 1 == b.depth);
       if (last) {
         // children are leaves: scan every qualifying one nearest-first; the boxes stay in registers
@@ -135,12 +173,7 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
         }
         // pop
         fresh = false;
-        if (level == 0) {
-          done = true;
-        } else {
-          level--;
-          node = (node - 1) / kFan;
-        }
+        if (!nn_pop(pend, node, level)) done = true;
       } else if (mask) {
         const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
         const int c = (int)(group8_min_u32(key) & 7u);
@@ -151,17 +184,12 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
         fresh = true;
       } else {
         fresh = false;
-        if (level == 0) {
-          done = true;
-        } else {
-          level--;
-          node = (node - 1) / kFan;
-        }
+        if (!nn_pop(pend, node, level)) done = true;
       }
     }
   }
 #ifdef DGS_NN_STEPS
-  best_idx = n_nodes * 1000 + n_leaves;
+  best_idx = n_wasted * 1000000 + n_nodes * 1000 + n_leaves;
 #endif
 }
 
