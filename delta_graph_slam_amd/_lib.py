@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "libdgs_reg.so")
 DGS_OK = 0
 STATUS = {0: "DGS_OK", 1: "DGS_ERR_INVALID_ARGUMENT", 2: "DGS_ERR_HIP", 3: "DGS_ERR_NO_TARGET", 4: "DGS_ERR_NO_SOURCE",
           5: "DGS_ERR_GRID_TOO_LARGE", 6: "DGS_ERR_UNSUPPORTED"}
-METHOD_NDT, METHOD_GICP = 0, 1
+METHOD_NDT, METHOD_GICP, METHOD_VGICP = 0, 1, 2
+VGICP_SEARCH = {"DIRECT1": 0, "DIRECT7": 1, "DIRECT27": 2}
 NDT_SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
 GICP_REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
 K_NDT_DERIVATIVES, K_NDT_SOLVE, K_NDT_VOXEL_BUILD, K_NN_SEARCH, K_GICP_LINEARIZE, K_GICP_COVARIANCE, K_TRANSFORM = range(7)
@@ -33,6 +34,7 @@ class Params(C.Structure):
         ("gicp_max_correspondence_distance", C.c_double), ("gicp_rotation_epsilon", C.c_double),
         ("gicp_lm_init_lambda_factor", C.c_double), ("gicp_correspondence_randomness", C.c_int32),
         ("gicp_regularization", C.c_int32), ("gicp_optimizer", C.c_int32), ("gicp_lm_max_iterations", C.c_int32),
+        ("vgicp_search_method", C.c_int32), ("vgicp_resolution", C.c_double),
     ]
 
 
@@ -48,7 +50,7 @@ SYMBOLS = [
     "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_align_batch", "dgs_calc_fitness_score", "dgs_voxel_grid_filter", "dgs_cloud_create", "dgs_cloud_destroy", "dgs_cloud_size",
     "dgs_set_input_target_cloud", "dgs_set_input_source_cloud", "dgs_align_batch_clouds", "dgs_profile_enable",
     "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_get_voxels",
-    "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize",
+    "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize", "dgs_vgicp_get_voxels",
 ]
 
 _lib = None
@@ -100,5 +102,6 @@ def load():
     lib.dgs_ndt_get_trajectory.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, P(C.c_int32)]
     lib.dgs_gicp_get_covariances.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.dgs_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, P(C.c_double), C.c_void_p, C.c_void_p]
+    lib.dgs_vgicp_get_voxels.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int64)]
     _lib = lib
     return lib

@@ -102,6 +102,24 @@ struct GicpPair {
   float final_T[16];  // column-major
 };
 
+// ---- FAST_VGICP target model: GaussianVoxelMap (ADDITIVE) ----------------------------------------------------------------
+struct VgicpVoxel {   // 96 B, six aligned 16-B loads
+  double mean[3];     // sum of the voxel's points / n
+  double w;           // sqrt(n): weight of a correspondence with this voxel
+  double cov[6];      // sum of the points' regularised covariances / n: xx, xy, xz, yy, yz, zz
+  int n, coord[3];    // points in the voxel; voxel coordinate floor(x / resolution - 0.5)
+};
+
+struct VgicpMap {
+  int min_c[3], div[3];  // coordinate of cell 0 and grid extents (from the target's AABB)
+  int mul1, mul2;
+  double resolution;
+  const int* cell2vox;   // dense [div0 * div1 * div2] -> voxel id or -1
+  const VgicpVoxel* vox;
+  int n_offsets;         // 1 / 7 / 27 voxels searched per source point
+  int search;            // dgs_vgicp_search
+};
+
 struct GicpItem {  // one registration of a batch: its source cloud (with index and covariances) and its work arrays
   const float4* src;         // source points in the caller's order
   const float4* src_sorted;  // the same points in their own index's Hilbert order, w = original index

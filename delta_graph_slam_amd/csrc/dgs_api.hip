@@ -149,13 +149,17 @@ int dgs_params_init(dgs_params* p, int32_t method) {
   p->gicp_regularization = DGS_GICP_REG_PLANE;
   p->gicp_optimizer = DGS_GICP_OPT_LEVENBERG_MARQUARDT;
   p->gicp_lm_max_iterations = 10;
-  if (method != DGS_METHOD_NDT && method != DGS_METHOD_GICP) return DGS_ERR_INVALID_ARGUMENT;
+  p->vgicp_search_method = DGS_VGICP_DIRECT1;
+  p->vgicp_resolution = 1.0;
+  if (method != DGS_METHOD_NDT && method != DGS_METHOD_GICP && method != DGS_METHOD_VGICP) return DGS_ERR_INVALID_ARGUMENT;
   return DGS_OK;
 }
 
 int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (!params || !out || params->struct_size != sizeof(dgs_params)) return DGS_ERR_INVALID_ARGUMENT;
-  if (params->method != DGS_METHOD_NDT && params->method != DGS_METHOD_GICP) return DGS_ERR_INVALID_ARGUMENT;
+  if (params->method != DGS_METHOD_NDT && params->method != DGS_METHOD_GICP && params->method != DGS_METHOD_VGICP) return DGS_ERR_INVALID_ARGUMENT;
+  if (params->method == DGS_METHOD_VGICP && (!(params->vgicp_resolution > 0) || params->vgicp_search_method < 0 || params->vgicp_search_method > DGS_VGICP_DIRECT27))
+    return DGS_ERR_INVALID_ARGUMENT;
   if (!(params->ndt_resolution > 0) || params->maximum_iterations < 0 || params->gicp_correspondence_randomness < 1) return DGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   dgs_handle* h = new (std::nothrow) dgs_handle();
@@ -187,7 +191,7 @@ void dgs_destroy(dgs_handle* h) {
   unbind(h, h->src_cloud);
   h->own_target.release(); h->own_source.release();
   for (auto& c : h->batch_clouds) c.release();
-  h->gitems.release();
+  h->gitems.release(); h->vvox.release(); h->vcell2vox.release();
   h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
@@ -233,6 +237,7 @@ int dgs_set_input_target(dgs_handle* h, const float* xyz16, int64_t n, int32_t o
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_target = false;
+  h->vmap_valid = false;
   unbind(h, h->tgt_cloud);
   h->tgt = &h->own_target;
   h->tgt->invalidate();
@@ -307,6 +312,7 @@ int dgs_set_input_target_cloud(dgs_handle* h, dgs_cloud* c) {
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_target = false;
+  h->vmap_valid = false;
   bind(h, h->tgt_cloud, c);
   h->tgt = &c->st;
   h->nt = c->st.n;
@@ -692,16 +698,25 @@ int dgs_gicp_get_covariances(dgs_handle* h, int32_t which, double* cov9) {
   if (!h || !cov9) return DGS_ERR_INVALID_ARGUMENT;
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
-  if (h->prm.method != DGS_METHOD_GICP) return DGS_ERR_UNSUPPORTED;
+  if (h->prm.method != DGS_METHOD_GICP && h->prm.method != DGS_METHOD_VGICP) return DGS_ERR_UNSUPPORTED;
   if (which ? (!h->have_target || h->nt == 0) : (!h->have_source || h->ns == 0)) return which ? DGS_ERR_NO_TARGET : DGS_ERR_NO_SOURCE;
   return gicp_covariances(h, which, cov9, which ? h->nt : h->ns);
+}
+
+int dgs_vgicp_get_voxels(dgs_handle* h, int64_t capacity, int32_t* coord3, int32_t* counts, double* mean3, double* cov9, int64_t* n_voxels) {
+  if (!h || !n_voxels || capacity < 0) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (h->prm.method != DGS_METHOD_VGICP) return DGS_ERR_UNSUPPORTED;
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (!h->have_target) return DGS_ERR_NO_TARGET;
+  return vgicp_voxels(h, capacity, coord3, counts, mean3, cov9, n_voxels);
 }
 
 int dgs_gicp_linearize(dgs_handle* h, const double* T16_rowmajor, int32_t error_only, double* error, double* hess36, double* b6) {
   if (!h || !T16_rowmajor || !error || (!error_only && (!hess36 || !b6))) return DGS_ERR_INVALID_ARGUMENT;
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
-  if (h->prm.method != DGS_METHOD_GICP) return DGS_ERR_UNSUPPORTED;
+  if (h->prm.method != DGS_METHOD_GICP && h->prm.method != DGS_METHOD_VGICP) return DGS_ERR_UNSUPPORTED;
   if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
   if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
   return gicp_probe(h, T16_rowmajor, error_only, error, hess36, b6);

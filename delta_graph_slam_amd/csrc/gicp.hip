@@ -152,6 +152,91 @@ __global__ __launch_bounds__(kBlock) void gicp_correspond_kernel(const BvhView b
   }
 }
 
+// One correspondence's contribution to E = sum w e^T M e, b = sum w J^T M e, H = sum w J^T M J with J = [skew(t) | -I]
+// (t = T p, e = mean_B - t; FastGICP: w = 1, FastVGICP: w = sqrt(points in the voxel)).  acc: E, b[6], upper triangle of H.
+template <bool WEIGHTED>
+__device__ __forceinline__ void gicp_accumulate(double* acc, const double* M, const double e0, const double e1, const double e2, const double t0,
+                                                const double t1, const double t2, const double w, const bool full) {
+  double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2;
+  double m1 = M[1] * e0 + M[3] * e1 + M[4] * e2;
+  double m2 = M[2] * e0 + M[4] * e1 + M[5] * e2;
+  double err = e0 * m0 + e1 * m1 + e2 * m2;
+  if (WEIGHTED) err *= w;
+  acc[0] += err;
+  if (full) {
+    double Mw[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) Mw[k] = WEIGHTED ? w * M[k] : M[k];
+    if (WEIGHTED) { m0 *= w; m1 *= w; m2 *= w; }
+    // b = J^T M e = [ (Me) x t ; -Me ]
+    acc[1] += m1 * t2 - m2 * t1;
+    acc[2] += m2 * t0 - m0 * t2;
+    acc[3] += m0 * t1 - m1 * t0;
+    acc[4] += -m0;
+    acc[5] += -m1;
+    acc[6] += -m2;
+    // H = J^T M J = [[S^T M S, -S^T M], [-M S, M]] with S = skew(t):  G = M S (3x3), then S^T G and -G^T
+    const double Mf[9] = {Mw[0], Mw[1], Mw[2], Mw[1], Mw[3], Mw[4], Mw[2], Mw[4], Mw[5]};
+    const double Sk[9] = {0, -t2, t1, t2, 0, -t0, -t1, t0, 0};
+    double G[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) G[r * 3 + c] = Mf[r * 3 + 0] * Sk[0 * 3 + c] + Mf[r * 3 + 1] * Sk[1 * 3 + c] + Mf[r * 3 + 2] * Sk[2 * 3 + c];
+    double Hrr[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Hrr[r * 3 + c] = Sk[0 * 3 + r] * G[0 * 3 + c] + Sk[1 * 3 + r] * G[1 * 3 + c] + Sk[2 * 3 + r] * G[2 * 3 + c];
+    // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+    acc[7] += Hrr[0]; acc[8] += Hrr[1]; acc[9] += Hrr[2]; acc[10] += -G[0 * 3 + 0]; acc[11] += -G[1 * 3 + 0]; acc[12] += -G[2 * 3 + 0];
+    acc[13] += Hrr[4]; acc[14] += Hrr[5]; acc[15] += -G[0 * 3 + 1]; acc[16] += -G[1 * 3 + 1]; acc[17] += -G[2 * 3 + 1];
+    acc[18] += Hrr[8]; acc[19] += -G[0 * 3 + 2]; acc[20] += -G[1 * 3 + 2]; acc[21] += -G[2 * 3 + 2];
+    acc[22] += Mw[0]; acc[23] += Mw[1]; acc[24] += Mw[2];
+    acc[25] += Mw[3]; acc[26] += Mw[4];
+    acc[27] += Mw[5];
+  }
+}
+
+// Mahalanobis matrix of one correspondence: (C_B + R C_A R^T)^-1, symmetric 6-vector (3x3 block of upstream's 4x4)
+__device__ __forceinline__ void gicp_mahalanobis(const double* T, const double* CA, const double* CB, double* M) {
+  const double a0 = CA[0], a1 = CA[1], a2 = CA[2], a3 = CA[3], a4 = CA[4], a5 = CA[5];
+  double RC[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const double r0 = T[r * 4 + 0], r1 = T[r * 4 + 1], r2 = T[r * 4 + 2];
+    RC[r * 3 + 0] = r0 * a0 + r1 * a1 + r2 * a2;
+    RC[r * 3 + 1] = r0 * a1 + r1 * a3 + r2 * a4;
+    RC[r * 3 + 2] = r0 * a2 + r1 * a4 + r2 * a5;
+  }
+  double S[9];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) S[r * 3 + c] = RC[r * 3 + 0] * T[c * 4 + 0] + RC[r * 3 + 1] * T[c * 4 + 1] + RC[r * 3 + 2] * T[c * 4 + 2];
+  S[0] += CB[0]; S[1] += CB[1]; S[2] += CB[2]; S[3] += CB[1]; S[4] += CB[3]; S[5] += CB[4]; S[6] += CB[2]; S[7] += CB[4]; S[8] += CB[5];
+  double Mi[9];
+  inv3_d(S, Mi);
+  M[0] = Mi[0]; M[1] = Mi[1]; M[2] = Mi[2]; M[3] = Mi[4]; M[4] = Mi[5]; M[5] = Mi[8];
+}
+
+// wave DPP sums -> LDS -> one fixed-order row of kAccumPad doubles per workgroup
+__device__ __forceinline__ void gicp_block_reduce(const double* acc, double* __restrict__ row) {
+  __shared__ double sm[kBlock / kWave][kAccumPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kAccum; k++) {
+    const double v = wave_sum_to_lane63(acc[k]);
+    if (lane == 63) sm[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumPad) {
+    double v = 0.0;
+    if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    row[threadIdx.x] = v;
+  }
+}
+
 // ================================================================================================ K6 linearize / error
 __global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const GicpItem* __restrict__ items, const float4* __restrict__ tgt,
                                                                 const double* __restrict__ cov_t, const GicpPair* __restrict__ pairs,
@@ -181,27 +266,7 @@ __global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const GicpItem* 
     const float4 pa = src[i], pb = tgt[j];
     double M[6];
     if (full) {
-      // RCR = C_B + R C_A R^T, Mahalanobis = RCR^-1 (3x3 block of upstream's 4x4)
-      const double* CA = cov_s + (size_t)i * 6;
-      const double* CB = cov_t + (size_t)j * 6;
-      const double a0 = CA[0], a1 = CA[1], a2 = CA[2], a3 = CA[3], a4 = CA[4], a5 = CA[5];
-      double RC[9];
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const double r0 = T[r * 4 + 0], r1 = T[r * 4 + 1], r2 = T[r * 4 + 2];
-        RC[r * 3 + 0] = r0 * a0 + r1 * a1 + r2 * a2;
-        RC[r * 3 + 1] = r0 * a1 + r1 * a3 + r2 * a4;
-        RC[r * 3 + 2] = r0 * a2 + r1 * a4 + r2 * a5;
-      }
-      double S[9];
-#pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) S[r * 3 + c] = RC[r * 3 + 0] * T[c * 4 + 0] + RC[r * 3 + 1] * T[c * 4 + 1] + RC[r * 3 + 2] * T[c * 4 + 2];
-      S[0] += CB[0]; S[1] += CB[1]; S[2] += CB[2]; S[3] += CB[1]; S[4] += CB[3]; S[5] += CB[4]; S[6] += CB[2]; S[7] += CB[4]; S[8] += CB[5];
-      double Mi[9];
-      inv3_d(S, Mi);
-      M[0] = Mi[0]; M[1] = Mi[1]; M[2] = Mi[2]; M[3] = Mi[4]; M[4] = Mi[5]; M[5] = Mi[8];
+      gicp_mahalanobis(T, cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, M);
       double* mo = mahal + (size_t)i * 6;
 #pragma unroll
       for (int k = 0; k < 6; k++) mo[k] = M[k];
@@ -214,56 +279,79 @@ __global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const GicpItem* 
     const double t0 = T[0] * ax + T[1] * ay + T[2] * az + T[3];
     const double t1 = T[4] * ax + T[5] * ay + T[6] * az + T[7];
     const double t2 = T[8] * ax + T[9] * ay + T[10] * az + T[11];
-    const double e0 = (double)pb.x - t0, e1 = (double)pb.y - t1, e2 = (double)pb.z - t2;
-    const double m0 = M[0] * e0 + M[1] * e1 + M[2] * e2;
-    const double m1 = M[1] * e0 + M[3] * e1 + M[4] * e2;
-    const double m2 = M[2] * e0 + M[4] * e1 + M[5] * e2;
-    acc[0] += e0 * m0 + e1 * m1 + e2 * m2;
-    if (full) {
-      // J = [ skew(t) | -I ];  b = J^T M e = [ (Me) x t ; -Me ]
-      acc[1] += m1 * t2 - m2 * t1;
-      acc[2] += m2 * t0 - m0 * t2;
-      acc[3] += m0 * t1 - m1 * t0;
-      acc[4] += -m0;
-      acc[5] += -m1;
-      acc[6] += -m2;
-      // H = J^T M J = [[S^T M S, -S^T M], [-M S, M]] with S = skew(t):  G = M S (3x3), then S^T G and -G^T
-      const double Mf[9] = {M[0], M[1], M[2], M[1], M[3], M[4], M[2], M[4], M[5]};
-      const double Sk[9] = {0, -t2, t1, t2, 0, -t0, -t1, t0, 0};
-      double G[9];
+    gicp_accumulate<false>(acc, M, (double)pb.x - t0, (double)pb.y - t1, (double)pb.z - t2, t0, t1, t2, 1.0, full);
+  }
+  gicp_block_reduce(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
+}
+
+// ================================================================================================ FAST_VGICP linearize / error
+// FastVGICP::update_correspondences + linearize (eval_kind 0) or compute_error (eval_kind 1) in one pass: the voxel of T p
+// (double) and its DIRECT1 / 7 / 27 neighbours are looked up in the dense cell table -- no tree, no distance gate --, every hit is
+// a correspondence with Mahalanobis (cov_voxel + R cov_p R^T)^-1 and weight sqrt(points in the voxel).  An error-only
+// evaluation re-uses the voxel ids and Mahalanobis matrices stored by the last linearisation, as upstream does.
+__global__ __launch_bounds__(kBlock) void vgicp_linearize_kernel(const GicpItem* __restrict__ items, const VgicpMap m,
+                                                                 const GicpPair* __restrict__ pairs, double* __restrict__ partials,
+                                                                 const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks) {
+  int pair, slice, nblocks;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, nblocks)) return;
+  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = nblocks;
+  const GicpPair& st = pairs[pair];
+  const GicpItem it = items[pair];
+  const int n = it.n, no = m.n_offsets;
+  const bool full = st.eval_kind == 0;
+  double T[12];
 #pragma unroll
-      for (int r = 0; r < 3; r++)
+  for (int k = 0; k < 12; k++) T[k] = st.Teval[k];
+  double acc[kAccum];
 #pragma unroll
-        for (int c = 0; c < 3; c++) G[r * 3 + c] = Mf[r * 3 + 0] * Sk[0 * 3 + c] + Mf[r * 3 + 1] * Sk[1 * 3 + c] + Mf[r * 3 + 2] * Sk[2 * 3 + c];
-      // rr block: (S^T G)(r,c) = sum_k S(k,r) G(k,c)
-      double Hrr[9];
+  for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
+
+  for (int i = slice * kBlock + threadIdx.x; i < n; i += nblocks * kBlock) {
+    const float4 pa = it.src[i];
+    const double ax = pa.x, ay = pa.y, az = pa.z;
+    const double t0 = T[0] * ax + T[1] * ay + T[2] * az + T[3];
+    const double t1 = T[4] * ax + T[5] * ay + T[6] * az + T[7];
+    const double t2 = T[8] * ax + T[9] * ay + T[10] * az + T[11];
+    // GaussianVoxelMap::voxel_coord: floor(x / resolution - 0.5), relative to the table's first cell
+    const int c0 = (int)floor(t0 / m.resolution - 0.5) - m.min_c[0];
+    const int c1 = (int)floor(t1 / m.resolution - 0.5) - m.min_c[1];
+    const int c2 = (int)floor(t2 / m.resolution - 0.5) - m.min_c[2];
+    for (int k = 0; k < no; k++) {
+      const size_t slot = (size_t)i * no + k;
+      int v;
+      if (full) {
+        int dx = 0, dy = 0, dz = 0;
+        if (m.search == DGS_VGICP_DIRECT7) {  // (0,0,0) (1,0,0) (-1,0,0) (0,1,0) (0,-1,0) (0,0,1) (0,0,-1)
+          dx = (k == 1) - (k == 2);
+          dy = (k == 3) - (k == 4);
+          dz = (k == 5) - (k == 6);
+        } else if (m.search == DGS_VGICP_DIRECT27) {
+          dx = k / 9 - 1;
+          dy = (k / 3) % 3 - 1;
+          dz = k % 3 - 1;
+        }
+        const int x = c0 + dx, y = c1 + dy, z = c2 + dz;
+        v = -1;
+        if (x >= 0 && x < m.div[0] && y >= 0 && y < m.div[1] && z >= 0 && z < m.div[2]) v = m.cell2vox[x + y * m.mul1 + z * m.mul2];
+        it.corr[slot] = v;
+      } else {
+        v = it.corr[slot];
+      }
+      if (v < 0) continue;
+      const VgicpVoxel* vx = m.vox + v;
+      double M[6];
+      if (full) {
+        gicp_mahalanobis(T, it.cov_s + (size_t)i * 6, vx->cov, M);
 #pragma unroll
-      for (int r = 0; r < 3; r++)
+        for (int a = 0; a < 6; a++) it.mahal[slot * 6 + a] = M[a];
+      } else {
 #pragma unroll
-        for (int c = 0; c < 3; c++) Hrr[r * 3 + c] = Sk[0 * 3 + r] * G[0 * 3 + c] + Sk[1 * 3 + r] * G[1 * 3 + c] + Sk[2 * 3 + r] * G[2 * 3 + c];
-      // rt block: (-S^T M)(r,c) = -sum_k S(k,r) M(k,c) = -(G^T)(r,c) ... G = M S  =>  (M S)^T = S^T M  (M symmetric)
-      // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
-      acc[7] += Hrr[0]; acc[8] += Hrr[1]; acc[9] += Hrr[2]; acc[10] += -G[0 * 3 + 0]; acc[11] += -G[1 * 3 + 0]; acc[12] += -G[2 * 3 + 0];
-      acc[13] += Hrr[4]; acc[14] += Hrr[5]; acc[15] += -G[0 * 3 + 1]; acc[16] += -G[1 * 3 + 1]; acc[17] += -G[2 * 3 + 1];
-      acc[18] += Hrr[8]; acc[19] += -G[0 * 3 + 2]; acc[20] += -G[1 * 3 + 2]; acc[21] += -G[2 * 3 + 2];
-      acc[22] += M[0]; acc[23] += M[1]; acc[24] += M[2];
-      acc[25] += M[3]; acc[26] += M[4];
-      acc[27] += M[5];
+        for (int a = 0; a < 6; a++) M[a] = it.mahal[slot * 6 + a];
+      }
+      gicp_accumulate<true>(acc, M, vx->mean[0] - t0, vx->mean[1] - t1, vx->mean[2] - t2, t0, t1, t2, vx->w, full);
     }
   }
-  __shared__ double sm[kBlock / kWave][kAccumPad];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kAccum; k++) {
-    const double v = wave_sum_to_lane63(acc[k]);
-    if (lane == 63) sm[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccumPad) {
-    double v = 0.0;
-    if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    partials[((size_t)pair * cap_blocks + slice) * kAccumPad + threadIdx.x] = v;
-  }
+  gicp_block_reduce(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
 }
 
 // ================================================================================================ solver
@@ -507,6 +595,14 @@ static void fill_gconsts(dgs_handle* h) {
   c.regularization = p.gicp_regularization;
 }
 
+static void fill_gconsts(dgs_handle* h);
+static int ensure_covariance(dgs_handle* h, CloudState& c);
+
+int gicp_ensure_target_covariance(dgs_handle* h) {
+  fill_gconsts(h);
+  return ensure_covariance(h, *h->tgt);
+}
+
 static int ensure_covariance(dgs_handle* h, CloudState& c) {
   if (c.cov_valid && c.cov_k == h->gconsts.k && c.cov_reg == h->gconsts.regularization) return DGS_OK;
   if (h->gconsts.k > kKnnMax) {
@@ -546,6 +642,15 @@ static GicpLaunch gicp_choose_launch(int n_pairs, int64_t max_n) {
 }
 
 static void gicp_launch_round(dgs_handle* h, const GicpLaunch& L) {
+  if (h->prm.method == DGS_METHOD_VGICP) {
+    int slot = prof_begin(h, DGS_K_GICP_LINEARIZE);
+    hipLaunchKernelGGL(vgicp_linearize_kernel, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->vmap, h->gpairs.ptr, h->partials.ptr,
+                       L.n_pairs, L.cap_l, h->pair_blocks.ptr);
+    prof_end(h, DGS_K_GICP_LINEARIZE, slot);
+    hipLaunchKernelGGL(gicp_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, h->pair_blocks.ptr, L.cap_l,
+                       h->gconsts, h->done_counter.ptr);
+    return;
+  }
   const BvhView v = make_bvh_view(h->tgt->bvh);
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
   hipLaunchKernelGGL(gicp_correspond_kernel, dim3(L.grid_c), dim3(kBlock), 0, h->stream, v, h->gitems.ptr, h->gpairs.ptr, L.n_pairs, L.cap_c,
@@ -579,6 +684,12 @@ static int gicp_start(dgs_handle* h, int n, CloudState* const* srcs, const doubl
   fill_gconsts(h);
   int rc = ensure_covariance(h, *h->tgt);
   if (rc) return rc;
+  const bool vgicp = h->prm.method == DGS_METHOD_VGICP;
+  if (vgicp && !h->vmap_valid) {
+    rc = vgicp_build_map(h);
+    if (rc) return rc;
+  }
+  const int64_t per_point = vgicp ? h->vmap.n_offsets : 1;  // correspondences per source point
   int64_t total = 0, max_n = 1;
   *n_live = 0;
   for (int i = 0; i < n; i++) {
@@ -591,9 +702,9 @@ static int gicp_start(dgs_handle* h, int n, CloudState* const* srcs, const doubl
   }
   const GicpLaunch L = gicp_choose_launch(n, max_n);
   *L_out = L;
-  DGS_HIP_TRY(h, h->corr.reserve((size_t)std::max<int64_t>(total, 1)));
+  DGS_HIP_TRY(h, h->corr.reserve((size_t)std::max<int64_t>(total, 1) * per_point));
   DGS_HIP_TRY(h, h->corr_sq.reserve((size_t)std::max<int64_t>(total, 1)));
-  DGS_HIP_TRY(h, h->mahal.reserve((size_t)std::max<int64_t>(total, 1) * 6));
+  DGS_HIP_TRY(h, h->mahal.reserve((size_t)std::max<int64_t>(total, 1) * per_point * 6));
   DGS_HIP_TRY(h, h->gpairs.reserve(n));
   DGS_HIP_TRY(h, h->gitems.reserve(n));
   DGS_HIP_TRY(h, h->inits.reserve(n));  // sizeof(NdtInit) >= sizeof(GicpInit)
@@ -616,9 +727,9 @@ static int gicp_start(dgs_handle* h, int n, CloudState* const* srcs, const doubl
     hit[i].src = c.pts.ptr;
     hit[i].src_sorted = c.bvh.sorted.ptr;
     hit[i].cov_s = c.cov.ptr;
-    hit[i].corr = h->corr.ptr + off;
+    hit[i].corr = h->corr.ptr + off * per_point;
     hit[i].corr_sq = h->corr_sq.ptr + off;
-    hit[i].mahal = h->mahal.ptr + off * 6;
+    hit[i].mahal = h->mahal.ptr + off * per_point * 6;
     hit[i].n = (int)c.n;
     hit[i].pad = 0;
     off += c.n;

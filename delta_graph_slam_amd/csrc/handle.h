@@ -125,6 +125,12 @@ struct dgs_handle {
   dgs::DevBuf<double> mahal;                   // 6 doubles per source point
   dgs::DevBuf<dgs::GicpPair> gpairs;
   dgs::DevBuf<dgs::GicpItem> gitems;
+  // FAST_VGICP target model
+  dgs::VgicpMap vmap{};
+  dgs::DevBuf<dgs::VgicpVoxel> vvox;
+  dgs::DevBuf<int> vcell2vox;
+  bool vmap_valid = false;
+  int64_t vmap_voxels = 0;
   std::vector<dgs::CloudState> batch_clouds;   // index + covariances of sources handed to dgs_align_batch as raw arrays
   dgs::GicpConsts gconsts{};
 
@@ -159,6 +165,9 @@ int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const floa
                         const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
 // gicp.hip
+int vgicp_build_map(dgs_handle* h);  // vgicp_voxel.hip: needs the target covariances
+int vgicp_voxels(dgs_handle* h, int64_t capacity, int32_t* coord3, int32_t* counts, double* mean3, double* cov9, int64_t* n_voxels);
+int gicp_ensure_target_covariance(dgs_handle* h);
 int gicp_align(dgs_handle* h, const float* guess16, dgs_result* out);
 int gicp_align_batch(dgs_handle* h, int n, CloudState* const* srcs, const float* guesses16, dgs_result* out);
 const float* gicp_final_transforms(dgs_handle* h, size_t* stride_bytes);

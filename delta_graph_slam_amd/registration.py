@@ -88,7 +88,7 @@ class Registration:
     def __init__(self, method: str = "NDT_OMP", device: int | None = None, **params):
         lib = L.load()
         self._lib = lib
-        m = L.METHOD_GICP if "GICP" in method else L.METHOD_NDT
+        m = L.METHOD_VGICP if "VGICP" in method else L.METHOD_GICP if "GICP" in method else L.METHOD_NDT
         p = L.Params()
         rc = lib.dgs_params_init(C.byref(p), m)
         if rc:
@@ -288,6 +288,18 @@ class Registration:
         return dict(target_points=out[0], source_points=out[1], valid_voxels=out[2], occupied_voxels=out[3],
                     grid_cells=out[4], evaluations=out[5])
 
+    def vgicp_voxels(self):
+        """FAST_VGICP target voxel map -> (coords [V,3], counts [V], means [V,3], covs [V,3,3]) in ascending (z, y, x) order"""
+        n = C.c_int64(0)
+        self._check(self._lib.dgs_vgicp_get_voxels(self._h, 0, None, None, None, None, C.byref(n)))
+        coords = np.zeros((n.value, 3), np.int32)
+        counts = np.zeros(n.value, np.int32)
+        means = np.zeros((n.value, 3))
+        covs = np.zeros((n.value, 3, 3))
+        self._check(self._lib.dgs_vgicp_get_voxels(self._h, n.value, coords.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p),
+                                                   means.ctypes.data_as(C.c_void_p), covs.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return coords, counts, means, covs
+
     def ndt_derivatives(self, p, T=None):
         p = np.ascontiguousarray(p, dtype=np.float64)
         t16 = None if T is None else _col16(T)
@@ -343,7 +355,8 @@ def select_registration_method(params: dict | None = None, device: int | None = 
     `params` plays the role of the private NodeHandle: keys are the reference's rosparam names
     (registration_method, reg_num_threads, reg_transformation_epsilon, reg_maximum_iterations,
     reg_max_correspondence_distance, reg_correspondence_randomness, reg_resolution, reg_nn_search_method).
-    "NDT_HIP" / "NDT_OMP" select NDT; "FAST_GICP_HIP" / "FAST_GICP" select GICP; unknown names warn and fall to NDT
+    "NDT_HIP" / "NDT_OMP" select NDT; "FAST_GICP_HIP" / "FAST_GICP" select GICP; "FAST_VGICP_HIP" / "FAST_VGICP" select the
+    voxelised GICP; unknown names warn and fall to NDT
     exactly like registrations.cpp:88-91.
     """
     pr = dict(params or {})
@@ -354,6 +367,9 @@ def select_registration_method(params: dict | None = None, device: int | None = 
     if method in ("FAST_GICP", "FAST_GICP_HIP"):
         return Registration("FAST_GICP", device=device,
                             gicp_max_correspondence_distance=float(pr.get("reg_max_correspondence_distance", 2.5)),
+                            gicp_correspondence_randomness=int(pr.get("reg_correspondence_randomness", 20)), **common)
+    if method in ("FAST_VGICP", "FAST_VGICP_HIP"):      # registrations.cpp:48-56
+        return Registration("FAST_VGICP", device=device, vgicp_resolution=float(pr.get("reg_resolution", 1.0)),
                             gicp_correspondence_randomness=int(pr.get("reg_correspondence_randomness", 20)), **common)
     if "NDT" not in method:
         import sys

@@ -56,7 +56,8 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
 
   // ---- the setters registrations.cpp calls on ndt_omp / fast_gicp objects (:30-34, :106-118) ----
   void setNumThreads(int n) { params_.num_threads = n; dirty_ = true; }
-  void setResolution(float r) { params_.ndt_resolution = r; dirty_ = true; }
+  void setResolution(float r) { params_.ndt_resolution = r; params_.vgicp_resolution = r; dirty_ = true; }  // NDT leaf / VGICP voxel size
+  void setNeighborSearchMethod(int method) { params_.vgicp_search_method = method; dirty_ = true; }        // FastVGICP (dgs_vgicp_search)
   void setNeighborhoodSearchMethod(int method) { params_.ndt_search_method = method; dirty_ = true; }  // dgs_ndt_search == pclomp order
   void setCorrespondenceRandomness(int k) { params_.gicp_correspondence_randomness = k; dirty_ = true; }
   void setStepSize(double s) { params_.ndt_step_size = s; dirty_ = true; }

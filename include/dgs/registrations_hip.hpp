@@ -29,6 +29,17 @@ typename pcl::Registration<PointT, PointT>::Ptr select_hip_registration(const st
     gicp->setCorrespondenceRandomness(pnh.template param<int>("reg_correspondence_randomness", 20));      // :34
     return base;
   }
+  if (registration_method == "FAST_VGICP_HIP") {
+    std::cout << "registration: FAST_VGICP_HIP" << std::endl;
+    typename pcl::Registration<PointT, PointT>::Ptr base(new Reg(DGS_METHOD_VGICP));
+    Reg* vgicp = static_cast<Reg*>(base.get());
+    vgicp->setNumThreads(pnh.template param<int>("reg_num_threads", 0));                                  // registrations.cpp:51
+    vgicp->setResolution(static_cast<float>(pnh.template param<double>("reg_resolution", 1.0)));          // :52
+    vgicp->setTransformationEpsilon(pnh.template param<double>("reg_transformation_epsilon", 0.01));      // :53
+    vgicp->setMaximumIterations(pnh.template param<int>("reg_maximum_iterations", 64));                   // :54
+    vgicp->setCorrespondenceRandomness(pnh.template param<int>("reg_correspondence_randomness", 20));     // :55
+    return base;
+  }
   if (registration_method == "NDT_HIP") {
     const double ndt_resolution = pnh.template param<double>("reg_resolution", 0.5);                      // :93
     const std::string nn_search_method = pnh.template param<std::string>("reg_nn_search_method", "DIRECT7");  // :103

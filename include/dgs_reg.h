@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 1
+#define DGS_ABI_VERSION 2
 
 typedef struct dgs_handle dgs_handle;
 typedef struct dgs_cloud dgs_cloud; /* a cloud resident in HBM together with its NN index / covariances (see below) */
@@ -46,8 +46,12 @@ enum dgs_status {
 /* registration_method strings of registrations.cpp:26-124 that this library serves */
 enum dgs_method {
   DGS_METHOD_NDT = 0,  /* "NDT_OMP": pclomp::NormalDistributionsTransform, registrations.cpp:101-120 */
-  DGS_METHOD_GICP = 1  /* "FAST_GICP": fast_gicp::FastGICP, registrations.cpp:27-36 */
+  DGS_METHOD_GICP = 1, /* "FAST_GICP": fast_gicp::FastGICP, registrations.cpp:27-36 */
+  DGS_METHOD_VGICP = 2 /* "FAST_VGICP": fast_gicp::FastVGICP, registrations.cpp:48-56 */
 };
+
+/* fast_gicp::NeighborSearchMethod of FastVGICP (voxel offsets searched around the voxel of T * p) */
+enum dgs_vgicp_search { DGS_VGICP_DIRECT1 = 0, DGS_VGICP_DIRECT7 = 1, DGS_VGICP_DIRECT27 = 2 };
 
 /* pclomp::NeighborSearchMethod (registrations.cpp:113-119), same enumerator order as upstream */
 enum dgs_ndt_search { DGS_NDT_KDTREE = 0, DGS_NDT_DIRECT26 = 1, DGS_NDT_DIRECT7 = 2, DGS_NDT_DIRECT1 = 3 };
@@ -96,6 +100,9 @@ typedef struct dgs_params {
   int32_t gicp_regularization;             /* default DGS_GICP_REG_PLANE */
   int32_t gicp_optimizer;                  /* default DGS_GICP_OPT_LEVENBERG_MARQUARDT */
   int32_t gicp_lm_max_iterations;          /* default 10 */
+  /* FAST_VGICP (uses the gicp_* fields above except gicp_max_correspondence_distance: VGICP has no distance gate) */
+  int32_t vgicp_search_method;             /* default DGS_VGICP_DIRECT1 (FastVGICP constructor) */
+  double vgicp_resolution;                 /* setResolution(reg_resolution), factory default 1.0 (registrations.cpp:52) */
 } dgs_params;
 
 /* What the callers read back after align(): hasConverged(), getFinalTransformation(), and the
@@ -223,8 +230,11 @@ int dgs_ndt_get_voxels(dgs_handle* h, int64_t* n, int64_t* keys, int32_t* counts
 int dgs_gicp_get_covariances(dgs_handle* h, int32_t which, double* cov9);
 /* GICP FastGICP::linearize (error_only = 0: new correspondences at the pose; returns sum of errors, H 6x6, b 6) or
  * FastGICP::compute_error (error_only = 1: correspondences / Mahalanobis matrices of the last linearisation).
- * The pose is a row-major double 4x4 (Eigen::Isometry3d). */
+ * The pose is a row-major double 4x4 (Eigen::Isometry3d).  With DGS_METHOD_VGICP the same calls are FastVGICP's. */
 int dgs_gicp_linearize(dgs_handle* h, const double* T16_rowmajor, int32_t error_only, double* error, double* hess36, double* b6);
+/* Test hook (FAST_VGICP): the target's Gaussian voxel map in ascending (z, y, x) voxel-coordinate order: coord3 int32[3], counts,
+ * mean double[3], cov double[9] per voxel; *n_voxels is always set, arrays are filled when capacity suffices. */
+int dgs_vgicp_get_voxels(dgs_handle* h, int64_t capacity, int32_t* coord3, int32_t* counts, double* mean3, double* cov9, int64_t* n_voxels);
 
 #ifdef __cplusplus
 }

@@ -40,12 +40,13 @@ struct GicpResult {
 class GicpCpu {
  public:
   explicit GicpCpu(const GicpParams& p) : prm(p) {}
-  void set_target(const float* xyz16, int64_t n);
+  virtual ~GicpCpu() = default;
+  virtual void set_target(const float* xyz16, int64_t n);
   void set_source(const float* xyz16, int64_t n);
   GicpResult align(const float* guess_colmajor16);
   // single linearisation / error evaluation at a double 4x4 (row-major) pose, for tests
-  double linearize(const double* T4x4, double* H36, double* b6);
-  double compute_error(const double* T4x4);
+  virtual double linearize(const double* T4x4, double* H36, double* b6);
+  virtual double compute_error(const double* T4x4);
   void ensure_covariances();
 
   GicpParams prm;
@@ -58,7 +59,7 @@ class GicpCpu {
   std::vector<double> mahal;  // 9 per source point
   int evaluations = 0;
 
- private:
+ protected:
   void calc_covariances(const std::vector<float>& cloud, int64_t n, const KdTree& tree, std::vector<double>& covs);
   void update_correspondences(const double* T);
   int threads() const;

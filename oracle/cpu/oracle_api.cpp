@@ -3,6 +3,7 @@
 #include "linalg.hpp"
 #include "ndt_cpu.hpp"
 #include "gicp_cpu.hpp"
+#include "vgicp_cpu.hpp"
 #include <cstring>
 #ifdef _OPENMP
 #include <omp.h>
@@ -141,6 +142,31 @@ void* orc_gicp_create(const orc_gicp_params* p) {
   d.lm_max_iterations = p->lm_max_iterations;
   d.num_threads = p->num_threads;
   return new GicpCpu(d);
+}
+static GicpParams gicp_params_from(const orc_gicp_params* p) {
+  GicpParams d;
+  d.transformation_epsilon = p->transformation_epsilon;
+  d.rotation_epsilon = p->rotation_epsilon;
+  d.max_correspondence_distance = p->max_correspondence_distance;
+  d.lm_init_lambda_factor = p->lm_init_lambda_factor;
+  d.max_iterations = p->max_iterations;
+  d.k_correspondences = p->k_correspondences;
+  d.regularization = p->regularization;
+  d.optimizer = p->optimizer;
+  d.lm_max_iterations = p->lm_max_iterations;
+  d.num_threads = p->num_threads;
+  return d;
+}
+/* FAST_VGICP: the returned object is used through the orc_gicp_* entry points */
+void* orc_vgicp_create(const orc_gicp_params* p, double resolution, int32_t search_method) {
+  return static_cast<GicpCpu*>(new VgicpCpu(gicp_params_from(p), resolution, search_method));
+}
+int64_t orc_vgicp_voxels(void* h, int32_t* coord3, int32_t* counts, double* mean3, double* cov9) {
+  VgicpCpu* v = dynamic_cast<VgicpCpu*>(static_cast<GicpCpu*>(h));
+  if (!v) return -1;
+  if (!v->map_valid) v->build_voxelmap();
+  if (coord3) v->dump_voxels(coord3, counts, mean3, cov9);
+  return v->voxel_count();
 }
 void orc_gicp_destroy(void* h) { delete static_cast<GicpCpu*>(h); }
 void orc_gicp_set_target(void* h, const float* xyz16, int64_t n) { static_cast<GicpCpu*>(h)->set_target(xyz16, n); }

@@ -42,6 +42,10 @@ typedef struct orc_gicp_params {
 } orc_gicp_params;
 void orc_gicp_default_params(orc_gicp_params* p);
 void* orc_gicp_create(const orc_gicp_params* p);
+/* FAST_VGICP (search_method 0 DIRECT1, 1 DIRECT7, 2 DIRECT27); drive it through the orc_gicp_* entry points */
+void* orc_vgicp_create(const orc_gicp_params* p, double resolution, int32_t search_method);
+/* voxel map dump in ascending (z, y, x) coordinate order; returns the voxel count (call with nulls first) */
+int64_t orc_vgicp_voxels(void* h, int32_t* coord3, int32_t* counts, double* mean3, double* cov9);
 void orc_gicp_destroy(void* h);
 void orc_gicp_set_target(void* h, const float* xyz16, int64_t n);
 void orc_gicp_set_source(void* h, const float* xyz16, int64_t n);

@@ -66,6 +66,9 @@ def lib(perturbed: bool = False):
         L.orc_ndt_voxels.restype = C.c_int64
         if hasattr(L, "orc_gicp_create"):
             L.orc_gicp_create.restype = C.c_void_p
+            if hasattr(L, "orc_vgicp_create"):
+                L.orc_vgicp_create.restype = C.c_void_p
+                L.orc_vgicp_voxels.restype = C.c_int64
             L.orc_gicp_linearize.restype = C.c_double
             L.orc_gicp_compute_error.restype = C.c_double
         if hasattr(L, "orc_fitness_score"):
@@ -248,8 +251,11 @@ class GicpOracle:
         p.lm_init_lambda_factor = lm_init_lambda_factor
         p.num_threads = num_threads
         self.params = p
-        self._h = C.c_void_p(L.orc_gicp_create(C.byref(p)))
+        self._h = self._create(L, p)
         self.ns = self.nt = 0
+
+    def _create(self, L, p):
+        return C.c_void_p(L.orc_gicp_create(C.byref(p)))
 
     def __del__(self):
         try:
@@ -296,6 +302,32 @@ class GicpOracle:
         sq = np.zeros(self.ns, np.float32)
         self._L.orc_gicp_correspondences(self._h, corr.ctypes.data_as(C.POINTER(C.c_int32)), sq.ctypes.data_as(C.POINTER(C.c_float)))
         return corr, sq
+
+
+VGICP_SEARCH = {"DIRECT1": 0, "DIRECT7": 1, "DIRECT27": 2}
+
+
+class VgicpOracle(GicpOracle):
+    """CPU restatement of fast_gicp::FastVGICP (registrations.cpp:48-56); same driver surface as GicpOracle."""
+
+    def __init__(self, resolution=1.0, search_method="DIRECT1", **kw):
+        self.resolution = float(resolution)
+        self.search_method = VGICP_SEARCH[search_method] if isinstance(search_method, str) else int(search_method)
+        super().__init__(**kw)
+
+    def _create(self, L, p):
+        return C.c_void_p(L.orc_vgicp_create(C.byref(p), C.c_double(self.resolution), C.c_int32(self.search_method)))
+
+    def voxels(self):
+        """-> (coords [V,3] int32, counts [V], means [V,3], covs [V,3,3]) in ascending (z, y, x) coordinate order"""
+        n = self._L.orc_vgicp_voxels(self._h, None, None, None, None)
+        coords = np.zeros((n, 3), np.int32)
+        counts = np.zeros(n, np.int32)
+        means = np.zeros((n, 3))
+        covs = np.zeros((n, 3, 3))
+        self._L.orc_vgicp_voxels(self._h, coords.ctypes.data_as(C.POINTER(C.c_int32)), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 means.ctypes.data_as(C.POINTER(C.c_double)), covs.ctypes.data_as(C.POINTER(C.c_double)))
+        return coords, counts, means, covs
 
 
 def fitness_score(target, source, T, max_range=1.7976931348623157e308, inlier_sq=0.25):

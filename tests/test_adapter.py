@@ -50,7 +50,8 @@ def test_adapter_compiles_links_and_fails_soft_without_a_gpu(driver, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("method,pyname,kw", [("NDT_HIP", "NDT_OMP", dict(ndt_resolution=1.0)),
-                                              ("FAST_GICP_HIP", "FAST_GICP", dict(gicp_max_correspondence_distance=2.0))])
+                                              ("FAST_GICP_HIP", "FAST_GICP", dict(gicp_max_correspondence_distance=2.0)),
+                                              ("FAST_VGICP_HIP", "FAST_VGICP", dict(vgicp_resolution=1.0))])
 def test_adapter_matches_python_mirror_on_gpu(driver, tmp_path, method, pyname, kw):
     from delta_graph_slam_amd.registration import Registration
     tgt, src, _ = synth.planar_pair(n=8192)
