@@ -83,6 +83,39 @@ def ndt_pair(name, tgt, src, res, guess, reps, cpu, orc, threads):
     return out
 
 
+def gicp_pair(name, method, tgt, src, guess, reps, cpu, orc, threads, **kw):
+    """Single align of a FAST_GICP / FAST_VGICP pair: first align (index + covariances + model build) and repeat aligns."""
+    import torch
+    from delta_graph_slam_amd.registration import Registration
+    reg = Registration(method, **kw)
+    dt_, ds_ = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
+
+    def cold():
+        reg.setInputTarget(dt_)
+        reg.setInputSource(ds_)
+        reg.align(guess)
+    t_cold, _ = timed(cold, reps)
+    t_warm, _ = timed(lambda: reg.align(guess), reps)
+    out = {"config": name, "points": int(src.shape[0]), "gpu_first_align_ms": 1e3 * t_cold, "gpu_repeat_align_ms": 1e3 * t_warm,
+           "iterations": reg.last_result.iterations, "evaluations": reg.last_result.evaluations, "converged": bool(reg.hasConverged())}
+    if cpu:
+        if method == "FAST_VGICP":
+            o = orc.VgicpOracle(resolution=kw.get("vgicp_resolution", 1.0), num_threads=threads)
+        else:
+            o = orc.GicpOracle(max_correspondence_distance=kw.get("gicp_max_correspondence_distance", 2.5), num_threads=threads)
+
+        def cpu_cold():
+            o.set_target(tgt)
+            o.set_source(src)
+            return o.align(guess)
+        ro = cpu_cold()
+        t_cpu, _ = timed(cpu_cold, 2, warm=0)
+        et, er = pose_error(reg.getFinalTransformation(), ro["T"])
+        out.update({"cpu_first_align_ms": 1e3 * t_cpu, "cpu_threads": threads, "speedup_first_align": t_cpu / t_cold,
+                    "vs_oracle_translation_m": et, "vs_oracle_rotation_rad": er, "oracle_iterations": ro["iterations"]})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=100)
@@ -107,6 +140,9 @@ def main():
     g[0, 3] -= 0.25
     g[1, 3] += 0.10
     print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, odometry-like guess (0.27 m off)", tgt, src, 1.0, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
+
+    print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_GICP dmax 2.5, odometry-like guess", "FAST_GICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
+    print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_VGICP res 1.0 DIRECT1, odometry-like guess", "FAST_VGICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th, vgicp_resolution=1.0)), flush=True)
 
     tgt, src, Tgt = synth.indoor_pair()
     print(json.dumps(ndt_pair("cfg5 indoor 200k pair, NDT 0.5 m, identity guess", tgt, src, 0.5, None, max(3, args.reps // 2), cpu, orc, th)), flush=True)
