@@ -548,13 +548,22 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
                                                            const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter) {
   const int pair = blockIdx.x;
   NdtPair* st = pairs + pair;
-  if (!st->active) return;
+  // Everything this kernel reads was written by the previous launch, i.e. comes from HBM: issue the independent loads (active
+  // flag, slice count, optimiser state) together instead of paying one memory round trip after the other.
+  const int active = st->active;
+  const int blocks_per_pair = pair_blocks[pair];  // slices the derivative launch gave this pair
+  NdtSolver s;
+  int need_h = 0;
+  if (threadIdx.x < kWave) {
+    s = st->s;
+    need_h = st->need_hessian;
+  }
+  if (!active) return;
   // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
   __shared__ double sm[kBlock / kAccumPad][kAccumPad];
   const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
   constexpr int G = kBlock / kAccumPad;
   double v = 0.0;
-  const int blocks_per_pair = pair_blocks[pair];  // slices the derivative launch gave this pair
   const double* base = partials + (size_t)pair * cap_blocks * kAccumPad;
   for (int b = grp; b < blocks_per_pair; b += G) v += base[(size_t)b * kAccumPad + col];
   sm[grp][col] = v;
@@ -570,8 +579,6 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
   if (threadIdx.x >= kWave) return;
   // ---- one wave advances the optimiser: state in registers, every lane computes the same values, lane 0 writes
   const bool writer = threadIdx.x == 0;
-  NdtSolver s = st->s;
-  const int need_h = st->need_hessian;
   s.score = tot[0];
 #pragma unroll
   for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];

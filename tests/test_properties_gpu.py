@@ -1,0 +1,109 @@
+"""-m gpu property tests at BASELINE.json's full sizes (65,536-point HDL-64E scans): statements that hold whatever the
+oracle says -- exactness of the NN index against a kd-tree, idempotence of align, recovery of a known rigid motion,
+invariance of the batched / sharded results under re-ordering of the candidates, warm-bound searches == cold searches."""
+import numpy as np
+import pytest
+
+from delta_graph_slam_amd import synth
+from tests.helpers import f32_sqdist, f32_transform, pose_error
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scans():
+    tgt, sources, guesses, gts = synth.loop_batch(n_candidates=6, n_points=65536, seed=77, distinct_scans=6)
+    return tgt, sources, guesses, gts
+
+
+def test_nn_index_is_exact_at_full_size_in_any_query_order(scans):
+    """nearestKSearch over 8 x 65,536 queries runs the kernel's 8 warm-bound rounds; every answer must still be the kd-tree's."""
+    from scipy.spatial import cKDTree
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, _, gts = scans
+    r = Registration("NDT_OMP")
+    r.setInputTarget(tgt)
+    tree = cKDTree(tgt[:, :3].astype(np.float64))
+    rng = np.random.default_rng(0)
+    qs = []
+    for s, T in zip(sources, gts):
+        q = np.ones_like(s)
+        q[:, :3] = f32_transform(T.astype(np.float32), s)
+        qs.append(q)
+    far = np.ones((65536, 4), np.float32)
+    far[:, :3] = rng.uniform(-120, 120, (65536, 3))           # queries far outside the cloud: unbounded traversal
+    qs.append(far)
+    qs.append(qs[0][rng.permutation(65536)])                  # no spatial coherence between consecutive queries
+    q = np.concatenate(qs, 0)
+    assert q.shape[0] == 8 * 65536
+    idx, sq = r.nearestKSearch(q)
+    _, nn = tree.query(q[:, :3].astype(np.float64), k=1)
+    d_tree = f32_sqdist(q[:, :3], tgt[nn, :3])
+    assert np.array_equal(sq, f32_sqdist(q[:, :3], tgt[idx, :3]))
+    assert np.all(sq <= d_tree)
+    assert (idx != nn).mean() < 1e-3
+    # a single 65,536-query call (one cold round) returns the same thing as the 8-round call
+    idx1, sq1 = r.nearestKSearch(qs[0])
+    assert np.array_equal(idx1, idx[:65536]) and np.array_equal(sq1, sq[:65536])
+
+
+@pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("FAST_GICP", dict(gicp_max_correspondence_distance=2.0)),
+                                       ("FAST_VGICP", dict(vgicp_resolution=1.0))])
+def test_align_is_idempotent_at_full_size(scans, method, kw):
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, gts = scans
+    r = Registration(method, **kw)
+    r.setInputTarget(tgt)
+    r.setInputSource(sources[0])
+    r.align(gts[0].astype(np.float32))          # start at the true pose: the optimum is nearby
+    assert r.hasConverged()
+    T1 = r.getFinalTransformation()
+    f1 = r.getFitnessScore()
+    r.align(T1)
+    assert r.hasConverged()
+    dt, dr = pose_error(r.getFinalTransformation(), T1)
+    assert dt < 2e-2 and dr < 2e-3, (dt, dr)    # within the stopping tolerance (eps 0.01) of the first answer
+    assert abs(r.getFitnessScore() - f1) <= 0.05 * f1
+    assert r.last_result.iterations <= 3
+    dt, dr = pose_error(T1, gts[0])
+    assert dt < 0.15 and dr < 1e-2
+
+
+@pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("FAST_GICP", dict()), ("FAST_VGICP", dict())])
+def test_known_rigid_motion_is_recovered_at_full_size(scans, method, kw):
+    """source = T_gt^-1 * target (same points): the optimum is T_gt itself, up to float rounding of the moved copy."""
+    from delta_graph_slam_amd.registration import Registration
+    tgt = scans[0]
+    T_gt = synth.make_transform((0.35, -0.2, 0.05), (0.01, -0.008, 0.03))
+    src = np.ones_like(tgt)
+    src[:, :3] = (tgt[:, :3].astype(np.float64) - T_gt[:3, 3]) @ T_gt[:3, :3]
+    r = Registration(method, transformation_epsilon=1e-4, **kw)
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    r.align()
+    assert r.hasConverged()
+    dt, dr = pose_error(r.getFinalTransformation(), T_gt)
+    tol_t, tol_r = (2e-3, 2e-4) if method == "NDT_OMP" else (5e-4, 5e-5)
+    assert dt < tol_t and dr < tol_r, (method, dt, dr)
+    assert r.getFitnessScore() < 1e-5
+
+
+@pytest.mark.parametrize("method", ["NDT_OMP", "FAST_GICP"])
+def test_batch_results_do_not_depend_on_candidate_order(scans, method):
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, _ = scans
+    r = Registration(method)
+    r.setInputTarget(tgt)
+    a = r.align_batch(sources, guesses)
+    perm = [3, 0, 5, 1, 4, 2]
+    b = r.align_batch([sources[p] for p in perm], [guesses[p] for p in perm])
+    for k, p in enumerate(perm):
+        assert a[p]["converged"] == b[k]["converged"]
+        dt, dr = pose_error(a[p]["T"], b[k]["T"])
+        # the same 6 pairs run in the same launches; only the pair -> workgroup dealing order moves
+        assert dt <= 1e-6 and dr <= 1e-7, (p, dt, dr)
+        assert abs(a[p]["fitness"] - b[k]["fitness"]) <= 1e-6 * abs(a[p]["fitness"])
+    # and a batch repeated is bit-identical
+    c = r.align_batch(sources, guesses)
+    for x, y in zip(a, c):
+        assert np.array_equal(x["T"], y["T"]) and x["fitness"] == y["fitness"]
