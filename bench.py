@@ -52,8 +52,10 @@ def main():
     ap.add_argument("--resolution", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget of the cpu_baseline sample")
-    ap.add_argument("--traffic", action="store_true",
-                    help="also measure HBM traffic of the dominant kernel: two child runs under rocprofv3 (--pmc FETCH_SIZE, then WRITE_SIZE)")
+    ap.add_argument("--traffic", dest="traffic", action="store_true", default=True,
+                    help="measure HBM traffic of the dominant kernel: two short child runs under rocprofv3 (--pmc FETCH_SIZE, then "
+                         "WRITE_SIZE); default at N=1 when rocprofv3 is on PATH")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false", help="leave roofline.traffic null (no rocprofv3 child runs)")
     ap.add_argument("--traffic-dir", default=os.path.join(ROOT, "gpurun_out", "traffic"))
     args = ap.parse_args()
 
@@ -238,7 +240,10 @@ def main():
                 "note": "reproducible = pairs on which the oracle agrees with itself to 1e-4 m / 1e-5 rad when compiled with FMA "
                         "contraction and when its float32 guess moves by +-1 ulp (DESIGN.md, NDT sensitivity)"}
         if world == 1 and args.traffic:
-            out["roofline"]["traffic"], out["roofline"]["traffic_detail"] = measure_traffic(args, bytes_per_eval)
+            try:
+                out["roofline"]["traffic"], out["roofline"]["traffic_detail"] = measure_traffic(args, bytes_per_eval)
+            except Exception as e:  # profiler missing / refused: the counter stays null, the bench line is still valid
+                out["roofline"]["traffic_detail"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -252,17 +257,26 @@ def measure_traffic(args, bytes_per_eval):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
     res = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(args.traffic_dir, counter)
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d, exist_ok=True)
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--pairs", str(args.pairs),
+               os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--pairs", str(args.pairs),
                "--points", str(args.points), "--distinct-scans", str(args.distinct_scans)]
         env = dict(os.environ, TMPDIR="/tmp")
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
+        child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            child.wait(timeout=240)
+        except subprocess.TimeoutExpired:  # end exactly the process group started here
+            os.killpg(child.pid, signal.SIGKILL)
+            child.wait()
+            return None, {"error": "rocprofv3 --pmc %s child timed out" % counter}
         tot, n = 0.0, 0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             per_dispatch = {}
