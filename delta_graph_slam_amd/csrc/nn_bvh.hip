@@ -170,18 +170,23 @@ __global__ __launch_bounds__(kBlock) void nn_fitness_kernel(const BvhView b, con
   }
 }
 
-__global__ void nn_fitness_final_kernel(const double* __restrict__ partial, int blocks_per_pair, int n_pairs, double* __restrict__ out) {
-  const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per pair: lane l sums rows l, l + 64, ... in order, then the lanes are summed in a fixed butterfly order
+__global__ __launch_bounds__(kWave) void nn_fitness_final_kernel(const double* __restrict__ partial, int blocks_per_pair, int n_pairs,
+                                                                 double* __restrict__ out) {
+  const int pair = blockIdx.x;
   if (pair >= n_pairs) return;
   double s = 0, c = 0, inl = 0;
-  for (int b = 0; b < blocks_per_pair; b++) {
+  for (int b = threadIdx.x; b < blocks_per_pair; b += kWave) {
     const double* r = partial + ((size_t)pair * blocks_per_pair + b) * 4;
     s += r[0]; c += r[1]; inl += r[2];
   }
-  out[pair * 4 + 0] = s;
-  out[pair * 4 + 1] = c;
-  out[pair * 4 + 2] = inl;
-  out[pair * 4 + 3] = 0;
+  s = wave_sum(s); c = wave_sum(c); inl = wave_sum(inl);
+  if (threadIdx.x == 0) {
+    out[pair * 4 + 0] = s;
+    out[pair * 4 + 1] = c;
+    out[pair * 4 + 2] = inl;
+    out[pair * 4 + 3] = 0;
+  }
 }
 
 // ---- host drivers ----------------------------------------------------------------------------------------------
@@ -286,7 +291,7 @@ int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const floa
   hipLaunchKernelGGL(nn_fitness_kernel, dim3(bpp, n_pairs), dim3(kBlock), 0, st, v, d_src_ptrs, d_sizes, d_T, T_stride_bytes, mr, iq,
                      h->nn_partials.ptr, bpp);
   prof_end(h, DGS_K_NN_SEARCH, slot);
-  hipLaunchKernelGGL(nn_fitness_final_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->nn_partials.ptr, bpp, n_pairs, d_out);
+  hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(n_pairs), dim3(kWave), 0, st, h->nn_partials.ptr, bpp, n_pairs, d_out);
   double* hout = reinterpret_cast<double*>(reinterpret_cast<char*>(h->pinned) + 4096);
   DGS_HIP_TRY(h, hipMemcpyAsync(hout, d_out, sizeof(double) * 4 * n_pairs, hipMemcpyDeviceToHost, st));
   DGS_HIP_TRY(h, hipStreamSynchronize(st));
