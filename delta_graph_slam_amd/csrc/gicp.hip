@@ -79,8 +79,8 @@ __global__ __launch_bounds__(kBlock) void gicp_covariance_kernel(const BvhView b
 #pragma unroll
   for (int r = 0; r < kKnnSlots; r++) {
     use[r] = (r * 8 + sub) < k;
-    const bool found = use[r] && L.d[r] < INFINITY;
-    const float4 p = found ? pts[L.id[r]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool found = use[r] && L.dist(r) < INFINITY;
+    const float4 p = found ? pts[L.index(r)] : make_float4(0.f, 0.f, 0.f, 0.f);
     px[r] = p.x; py[r] = p.y; pz[r] = p.z;
     if (use[r]) { sx += px[r]; sy += py[r]; sz += pz[r]; }
   }

@@ -195,15 +195,19 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
 
 
 
-// ---- exact k-NN for the 8-lane group (k <= 32): the k best (distance, index) pairs live in registers, 4 slots per lane,
-// sorted ascending over slot = r * 8 + sub.  Candidates are compared lexicographically on (distance, index), so the set
-// is deterministic; pruning tests the box distance against the current k-th best.
+// ---- exact k-NN for the 8-lane group (k <= 32): the k best (distance, index) pairs live in registers, 4 slots per lane, as an
+// UNSORTED set of 64-bit keys (distance bits << 32 | index): squared distances are non-negative floats, so unsigned key order is
+// the lexicographic (distance, index) order and the set is deterministic.  The set tracks its largest key (the k-th best);
+// a better candidate replaces it.  Every cross-lane step is a DPP min / max inside the group: no LDS traffic, no sorted
+// insertion (measured: the sorted list with bpermute shuffles spent more time inserting than traversing).
 constexpr int kKnnSlots = 4;
 constexpr int kKnnMax = kKnnSlots * 8;
 struct KnnList {
-  float d[kKnnSlots];
-  int id[kKnnSlots];
+  unsigned long long key[kKnnSlots];  // slot r * 8 + sub; slots >= k hold 0 (never the largest), empty slots hold (inf, ~slot)
+  __device__ __forceinline__ float dist(int r) const { return __uint_as_float((unsigned)(key[r] >> 32)); }
+  __device__ __forceinline__ int index(int r) const { return (int)(unsigned)key[r]; }
 };
+constexpr unsigned long long kKnnInvalid = ~0ull;
 
 __device__ __forceinline__ double group8_sum_f64(double v) {
   {
@@ -224,49 +228,41 @@ __device__ __forceinline__ double group8_sum_f64(double v) {
   return v;
 }
 
-__device__ __forceinline__ void knn_threshold(const KnnList& L, int k, int gshift, float& td, int& ti) {
-  const int rk = (k - 1) >> 3, lk = gshift + ((k - 1) & 7);
-  const float vd = (rk == 0) ? L.d[0] : (rk == 1) ? L.d[1] : (rk == 2) ? L.d[2] : L.d[3];
-  const int vi = (rk == 0) ? L.id[0] : (rk == 1) ? L.id[1] : (rk == 2) ? L.id[2] : L.id[3];
-  td = __shfl(vd, lk, 64);
-  ti = __shfl(vi, lk, 64);
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long group8_min_u64(unsigned long long v) {
+  v = min(v, dpp_u64<0xB1>(v));
+  v = min(v, dpp_u64<0x4E>(v));
+  v = min(v, dpp_u64<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ unsigned long long group8_max_u64(unsigned long long v) {
+  v = max(v, dpp_u64<0xB1>(v));
+  v = max(v, dpp_u64<0x4E>(v));
+  v = max(v, dpp_u64<0x141>(v));
+  return v;
 }
 
-__device__ __forceinline__ void knn_insert(KnnList& L, float cd, int ci, int sub, int gshift) {
-  int p = 0;
-#pragma unroll
-  for (int r = 0; r < kKnnSlots; r++) {
-    const bool lt = (L.d[r] < cd) || (L.d[r] == cd && L.id[r] < ci);
-    p += __popc((unsigned)((__ballot(lt) >> gshift) & 0xFFull));
-  }
-  float nd[kKnnSlots];
-  int ni[kKnnSlots];
-#pragma unroll
-  for (int r = 0; r < kKnnSlots; r++) {
-    // previous slot: lane sub-1 of the same row, or lane 7 of row r-1
-    float pd = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(L.d[r]), 0x111, 0xf, 0xf, false));  // row_shr:1
-    int pi = __builtin_amdgcn_update_dpp(0, L.id[r], 0x111, 0xf, 0xf, false);
-    if (r > 0) {
-      const float wd = __shfl(L.d[r - 1], gshift + 7, 64);
-      const int wi = __shfl(L.id[r - 1], gshift + 7, 64);
-      if (sub == 0) { pd = wd; pi = wi; }
-    }
-    const int slot = r * 8 + sub;
-    nd[r] = (slot > p) ? pd : (slot == p ? cd : L.d[r]);
-    ni[r] = (slot > p) ? pi : (slot == p ? ci : L.id[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < kKnnSlots; r++) { L.d[r] = nd[r]; L.id[r] = ni[r]; }
+// largest key of the set = the current k-th best (group-uniform)
+__device__ __forceinline__ unsigned long long knn_largest(const KnnList& L) {
+  return group8_max_u64(max(max(L.key[0], L.key[1]), max(L.key[2], L.key[3])));
 }
 
-// All 8 lanes of the group end with the same distributed list.  `alive` = false lanes follow the control flow only.
+// All 8 lanes of the group end with the same distributed set.  `alive` = false lanes follow the control flow only.
 __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7, gshift = lane & ~7;
 #pragma unroll
-  for (int r = 0; r < kKnnSlots; r++) { L.d[r] = INFINITY; L.id[r] = 0x7FFFFFFF; }
-  float td = INFINITY;
-  int ti = 0x7FFFFFFF;
+  for (int r = 0; r < kKnnSlots; r++) {
+    const int slot = r * 8 + sub;
+    L.key[r] = (slot < k) ? (((unsigned long long)__float_as_uint(INFINITY) << 32) | (unsigned)(0x7FFFFFFF - slot)) : 0ull;
+  }
+  unsigned long long worst = knn_largest(L);
+  float td = INFINITY;  // distance part of `worst`: boxes farther than this cannot hold a better point
   int node = 0, level = 0;
   unsigned long long pend = 0ull;
   bool fresh = true;
@@ -280,37 +276,32 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
       const bool last = (level + 1 == b.depth);
       if (last) {
         while (mask) {
-          const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-          const int c = (int)(group8_min_u32(key) & 7u);
+          const unsigned bkey = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+          const int c = (int)(group8_min_u32(bkey) & 7u);
           mask &= ~(1u << c);
           const int leaf = (node * kFan + 1 + c) - b.first_leaf;
           const float4 p = b.sorted[leaf * kLeaf + sub];
-          float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
-          if (!(dp == dp)) dp = INFINITY;
-          const int oi = (int)__float_as_uint(p.w);
-          unsigned pm = (unsigned)((__ballot((dp < td) || (dp == td && oi < ti)) >> gshift) & 0xFFull);
-          while (pm) {
-            const int c2 = __ffs((int)pm) - 1;
-            pm &= pm - 1u;
-            const float cd = __shfl(dp, gshift + c2, 64);
-            const int ci = __shfl(oi, gshift + c2, 64);
-            if ((cd < td) || (cd == td && ci < ti)) {
-              knn_insert(L, cd, ci, sub, gshift);
-              knn_threshold(L, k, gshift, td, ti);
-            }
+          const float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
+          // this lane's point as a candidate key; padding / non-finite points never qualify
+          unsigned long long cand = (dp < INFINITY) ? (((unsigned long long)__float_as_uint(dp) << 32) | __float_as_uint(p.w)) : kKnnInvalid;
+          if (!(cand < worst)) cand = kKnnInvalid;
+          // take the leaf's candidates smallest first: each one that gets in lowers the bar for the rest
+          while (__ballot(cand != kKnnInvalid) >> gshift & 0xFFull) {
+            const unsigned long long best = group8_min_u64(cand);
+#pragma unroll
+            for (int r = 0; r < kKnnSlots; r++)
+              if (L.key[r] == worst) L.key[r] = best;  // keys are unique: exactly one slot of one lane holds the largest
+            worst = knn_largest(L);
+            if (cand == best || !(cand < worst)) cand = kKnnInvalid;
           }
+          td = __uint_as_float((unsigned)(worst >> 32));
           mask &= (unsigned)((__ballot(d <= td) >> gshift) & 0xFFull);
         }
         fresh = false;
-        if (level == 0) {
-          done = true;
-        } else {
-          level--;
-          node = (node - 1) / kFan;
-        }
+        if (!nn_pop(pend, node, level)) done = true;
       } else if (mask) {
-        const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-        const int c = (int)(group8_min_u32(key) & 7u);
+        const unsigned bkey = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
+        const int c = (int)(group8_min_u32(bkey) & 7u);
         mask &= ~(1u << c);
         pend = (pend & ~(0xFFull << (8 * level))) | ((unsigned long long)mask << (8 * level));
         node = node * kFan + 1 + c;
@@ -318,12 +309,7 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
         fresh = true;
       } else {
         fresh = false;
-        if (level == 0) {
-          done = true;
-        } else {
-          level--;
-          node = (node - 1) / kFan;
-        }
+        if (!nn_pop(pend, node, level)) done = true;
       }
     }
   }
