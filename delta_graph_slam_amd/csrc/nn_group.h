@@ -83,17 +83,29 @@ __device__ __forceinline__ float group8_min_f32(float v) {
   return v;
 }
 
-// heap index of the first node of a level of the implicit 8-ary tree: (8^l - 1) / 7
-__device__ __forceinline__ int heap_first(int level) { return (int)(((1u << (3 * level)) - 1u) / 7u); }
+// heap index of the first node of a level of the implicit 8-ary tree: (8^l - 1) / 7 = 0b...001001001 below bit 3 l
+__device__ __forceinline__ int heap_first(int level) { return (int)(0x09249249u & ((1u << (3 * level)) - 1u)); }
 
-// Leaves `node` (at `level`) for the deepest shallower level that still has pending children; levels whose pending byte is
-// empty are skipped without touching their boxes.  Returns false when nothing is pending anywhere (the query is finished).
-__device__ __forceinline__ bool nn_pop(const unsigned long long pend, int& node, int& level) {
-  const unsigned long long pm = pend & ((1ull << (8 * level)) - 1ull);
-  if (pm == 0ull) return false;
-  const int up = (63 - __clzll((long long)pm)) >> 3;
+// Pending children of the levels ABOVE the node being visited, one byte per level (bit c: child c still qualifies).  Invariant:
+// the bytes of the current level and below are zero, so "anything left?" is pend != 0 and the deepest pending level is the top
+// set byte.  32 bits serve trees of up to 5 levels (262,144 points: the last level scans its leaves in place and needs no byte),
+// 64 bits the rest.
+template <class PT>
+__device__ __forceinline__ int pend_top_shift(PT pend);
+template <>
+__device__ __forceinline__ int pend_top_shift<unsigned>(unsigned pend) { return (31 - __clz((int)pend)) & ~7; }
+template <>
+__device__ __forceinline__ int pend_top_shift<unsigned long long>(unsigned long long pend) { return (63 - __clzll((long long)pend)) & ~7; }
+
+// Leaves `node` (level sh / 8) for the deepest shallower level that still has pending children; levels with nothing pending
+// are skipped without touching their boxes.  Returns false when nothing is pending anywhere (the query is finished).
+template <class PT>
+__device__ __forceinline__ bool nn_pop(const PT pend, int& node, int& sh) {
+  if (pend == 0) return false;
+  const int up_sh = pend_top_shift<PT>(pend);
+  const int level = sh >> 3, up = up_sh >> 3;
   node = heap_first(up) + ((node - heap_first(level)) >> (3 * (level - up)));
-  level = up;
+  sh = up_sh;
   return true;
 }
 
@@ -119,17 +131,24 @@ __device__ __forceinline__ float nn_warm_bound_round(float prev_best, bool prev_
 }
 
 // Exact 1-NN of (x, y, z) for the 8-lane group this lane belongs to; x, y, z must be equal across the group.
-// (Measured and rejected: keeping the child-box distances of every level in registers to skip the reload on the way
-// back up costs more select instructions than the L1-resident reload saves; the traversal is VALU-issue bound.)
-// All 8 lanes return the same (best, best_idx).  Lanes of a wave whose group is idle must still call this with
-// `alive` = false (they follow the control flow and touch no memory beyond node 0).
-__device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float y, float z, bool alive, float bound, float& best, int& best_idx) {
+// The traversal is VALU-issue bound (PMC: the fitness kernel keeps the VALUs 100 % busy at a 96 % L2 hit rate), so the loop is
+// written for instruction count: 32-bit pending word where the tree allows, no "which levels are stale" masking (see the
+// invariant above), unsigned-integer minima on the bit patterns of the non-negative distances, 32-bit load offsets.
+// (Measured and rejected: keeping the child-box distances of every level in registers to skip the reload on the way back up;
+// visiting a leaf like a node so that every step is uniform -- the re-visits of the last level cost more than the divergence.)
+// All 8 lanes return the same (best, best_idx); best_idx == 0x7FFFFFFF: nothing within `bound` (then best is meaningless).
+// Lanes of a wave whose group is idle must still call this with `alive` = false (they follow the control flow only).
+template <class PT>
+__device__ __forceinline__ void nn_query_group_t(const BvhView& b, float x, float y, float z, bool alive, float bound, float& best, int& best_idx) {
   const int lane = threadIdx.x & 63;
-  const int sub = lane & 7, gshift = lane & ~7;
-  best = bound;  // only points with squared distance <= bound are reported (INFINITY: unbounded)
+  const unsigned sub = lane & 7, gshift = lane & ~7, bit = 1u << sub;
+  // FLT_MAX instead of +inf: empty slots carry inverted boxes (distance +inf) and must never be entered, and "d <= best" then
+  // needs no second test; no finite cloud has squared distances beyond FLT_MAX
+  best = fminf(bound, FLT_MAX);
   best_idx = 0x7FFFFFFF;
-  int node = 0, level = 0;
-  unsigned long long pend = 0ull;  // one byte of not-yet-visited qualifying children per level
+  int node = 0, sh = 0;
+  const int last_sh = 8 * (b.depth - 1);
+  PT pend = 0;
   bool fresh = true;
   bool done = !alive;
 #ifdef DGS_NN_STEPS
@@ -140,51 +159,52 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
 #ifdef DGS_NN_STEPS
       n_nodes++;
 #endif
-      const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
+      const unsigned ofs = (unsigned)node * kFan + sub;
+      const float4 lo = b.box_lo[ofs], hi = b.box_hi[ofs];
       const float d = aabb_sqdist_rn(lo, hi, x, y, z);
-      // empty slots carry inverted boxes (distance +inf): never enter them, even while best is still +inf
-      unsigned mask = (unsigned)((__ballot(d <= best && d < INFINITY) >> gshift) & 0xFFull);
-      if (!fresh) mask &= (unsigned)((pend >> (8 * level)) & 0xFFull);
+      unsigned mask = (unsigned)(__ballot(d <= best) >> gshift) & 0xFFu;
+      if (!fresh) {  // back at a node: only the children noted as pending, and the note is consumed
+        mask &= (unsigned)(pend >> sh) & 0xFFu;
+        pend &= ~((PT)0xFFu << sh);
+      }
 #ifdef DGS_NN_STEPS
       if (!fresh && mask == 0) n_wasted++;
 #endif
-      const bool last = (level + 1 == b.depth);
-      if (last) {
+      if (sh == last_sh) {
         // children are leaves: scan every qualifying one nearest-first; the boxes stay in registers
         while (mask) {
-          const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-          const int c = (int)(group8_min_u32(key) & 7u);
+          const unsigned key = (mask & bit) ? ((__float_as_uint(d) & ~7u) | sub) : 0xFFFFFFFFu;
+          const unsigned c = group8_min_u32(key) & 7u;
           mask &= ~(1u << c);
 #ifdef DGS_NN_STEPS
           n_leaves++;
 #endif
-          const int leaf = (node * kFan + 1 + c) - b.first_leaf;
+          const unsigned leaf = ((unsigned)node * kFan + 1u + c) - (unsigned)b.first_leaf;
           const float4 p = b.sorted[leaf * kLeaf + sub];
-          float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
-          if (!(dp == dp)) dp = INFINITY;  // padding / non-finite points
-          const float dmin = group8_min_f32(dp);
-          const unsigned oi = (dp == dmin) ? __float_as_uint(p.w) : 0xFFFFFFFFu;
-          const unsigned imin = group8_min_u32(oi);
-          if (dmin < best || (dmin == best && (int)imin < best_idx)) {
-            best = dmin;
+          const float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
+          // non-negative floats order like their bit patterns; NaN (padding / non-finite points) sorts above +inf
+          const unsigned dbits = __float_as_uint(dp);
+          const unsigned dmin = group8_min_u32(dbits);
+          const unsigned imin = group8_min_u32((dbits == dmin) ? __float_as_uint(p.w) : 0xFFFFFFFFu);
+          const unsigned bbits = __float_as_uint(best);
+          if (dmin < bbits || (dmin == bbits && (int)imin < best_idx)) {
+            best = __uint_as_float(dmin);
             best_idx = (int)imin;
           }
-          mask &= (unsigned)((__ballot(d <= best) >> gshift) & 0xFFull);
+          mask &= (unsigned)(__ballot(d <= best) >> gshift) & 0xFFu;
         }
-        // pop
         fresh = false;
-        if (!nn_pop(pend, node, level)) done = true;
+        if (!nn_pop<PT>(pend, node, sh)) done = true;
       } else if (mask) {
-        const unsigned key = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-        const int c = (int)(group8_min_u32(key) & 7u);
-        mask &= ~(1u << c);
-        pend = (pend & ~(0xFFull << (8 * level))) | ((unsigned long long)mask << (8 * level));
-        node = node * kFan + 1 + c;
-        level++;
+        const unsigned key = (mask & bit) ? ((__float_as_uint(d) & ~7u) | sub) : 0xFFFFFFFFu;
+        const unsigned c = group8_min_u32(key) & 7u;
+        pend |= (PT)(mask & ~(1u << c)) << sh;
+        node = node * kFan + 1 + (int)c;
+        sh += 8;
         fresh = true;
       } else {
         fresh = false;
-        if (!nn_pop(pend, node, level)) done = true;
+        if (!nn_pop<PT>(pend, node, sh)) done = true;
       }
     }
   }
@@ -193,7 +213,12 @@ __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float 
 #endif
 }
 
-
+__device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float y, float z, bool alive, float bound, float& best, int& best_idx) {
+  if (b.depth <= 5)
+    nn_query_group_t<unsigned>(b, x, y, z, alive, bound, best, best_idx);
+  else
+    nn_query_group_t<unsigned long long>(b, x, y, z, alive, bound, best, best_idx);
+}
 
 // ---- exact k-NN for the 8-lane group (k <= 32): the k best (distance, index) pairs live in registers, 4 slots per lane, as an
 // UNSORTED set of 64-bit keys (distance bits << 32 | index): squared distances are non-negative floats, so unsigned key order is
@@ -263,7 +288,8 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
   }
   unsigned long long worst = knn_largest(L);
   float td = INFINITY;  // distance part of `worst`: boxes farther than this cannot hold a better point
-  int node = 0, level = 0;
+  int node = 0, sh = 0;
+  const int last_sh = 8 * (b.depth - 1);
   unsigned long long pend = 0ull;
   bool fresh = true;
   bool done = !alive;
@@ -272,8 +298,11 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
       const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
       const float d = aabb_sqdist_rn(lo, hi, x, y, z);
       unsigned mask = (unsigned)((__ballot(d <= td && d < INFINITY) >> gshift) & 0xFFull);
-      if (!fresh) mask &= (unsigned)((pend >> (8 * level)) & 0xFFull);
-      const bool last = (level + 1 == b.depth);
+      if (!fresh) {
+        mask &= (unsigned)((pend >> sh) & 0xFFull);
+        pend &= ~(0xFFull << sh);
+      }
+      const bool last = (sh == last_sh);
       if (last) {
         while (mask) {
           const unsigned bkey = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
@@ -298,18 +327,18 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
           mask &= (unsigned)((__ballot(d <= td) >> gshift) & 0xFFull);
         }
         fresh = false;
-        if (!nn_pop(pend, node, level)) done = true;
+        if (!nn_pop<unsigned long long>(pend, node, sh)) done = true;
       } else if (mask) {
         const unsigned bkey = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
         const int c = (int)(group8_min_u32(bkey) & 7u);
         mask &= ~(1u << c);
-        pend = (pend & ~(0xFFull << (8 * level))) | ((unsigned long long)mask << (8 * level));
+        pend |= (unsigned long long)mask << sh;
         node = node * kFan + 1 + c;
-        level++;
+        sh += 8;
         fresh = true;
       } else {
         fresh = false;
-        if (!nn_pop(pend, node, level)) done = true;
+        if (!nn_pop<unsigned long long>(pend, node, sh)) done = true;
       }
     }
   }
