@@ -53,6 +53,13 @@ __device__ __forceinline__ uint32_t hilbert30(float x, float y, float z, const f
   return (expand_bits10(X0) << 2) | (expand_bits10(X1) << 1) | expand_bits10(X2);
 }
 
+// 16-byte record at a 32-bit BYTE offset from a wave-uniform base: lets the load take the base from SGPRs and the offset from one
+// VGPR (global_load ... v_off, s[base]) instead of building a 64-bit address per lane (3 VALU instructions per load in a loop
+// that is VALU-issue bound).  The index structures are far below 4 GB.
+__device__ __forceinline__ float4 load16_at(const float4* __restrict__ base, unsigned index) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (index << 4));
+}
+
 __device__ __forceinline__ float sqdist_rn(float ax, float ay, float az, float bx, float by, float bz) {
   const float dx = sub_rn(ax, bx), dy = sub_rn(ay, by), dz = sub_rn(az, bz);
   return add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
@@ -160,7 +167,7 @@ __device__ __forceinline__ void nn_query_group_t(const BvhView& b, float x, floa
       n_nodes++;
 #endif
       const unsigned ofs = (unsigned)node * kFan + sub;
-      const float4 lo = b.box_lo[ofs], hi = b.box_hi[ofs];
+      const float4 lo = load16_at(b.box_lo, ofs), hi = load16_at(b.box_hi, ofs);
       const float d = aabb_sqdist_rn(lo, hi, x, y, z);
       unsigned mask = (unsigned)(__ballot(d <= best) >> gshift) & 0xFFu;
       if (!fresh) {  // back at a node: only the children noted as pending, and the note is consumed
@@ -180,7 +187,7 @@ __device__ __forceinline__ void nn_query_group_t(const BvhView& b, float x, floa
           n_leaves++;
 #endif
           const unsigned leaf = ((unsigned)node * kFan + 1u + c) - (unsigned)b.first_leaf;
-          const float4 p = b.sorted[leaf * kLeaf + sub];
+          const float4 p = load16_at(b.sorted, leaf * kLeaf + sub);
           const float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
           // non-negative floats order like their bit patterns; NaN (padding / non-finite points) sorts above +inf
           const unsigned dbits = __float_as_uint(dp);
@@ -295,7 +302,8 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
   bool done = !alive;
   while (__any(!done)) {
     if (!done) {
-      const float4 lo = b.box_lo[node * kFan + sub], hi = b.box_hi[node * kFan + sub];
+      const unsigned ofs = (unsigned)node * kFan + (unsigned)sub;
+      const float4 lo = load16_at(b.box_lo, ofs), hi = load16_at(b.box_hi, ofs);
       const float d = aabb_sqdist_rn(lo, hi, x, y, z);
       unsigned mask = (unsigned)((__ballot(d <= td && d < INFINITY) >> gshift) & 0xFFull);
       if (!fresh) {
@@ -308,8 +316,8 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
           const unsigned bkey = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
           const int c = (int)(group8_min_u32(bkey) & 7u);
           mask &= ~(1u << c);
-          const int leaf = (node * kFan + 1 + c) - b.first_leaf;
-          const float4 p = b.sorted[leaf * kLeaf + sub];
+          const unsigned leaf = (unsigned)((node * kFan + 1 + c) - b.first_leaf);
+          const float4 p = load16_at(b.sorted, leaf * kLeaf + (unsigned)sub);
           const float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
           // this lane's point as a candidate key; padding / non-finite points never qualify
           unsigned long long cand = (dp < INFINITY) ? (((unsigned long long)__float_as_uint(dp) << 32) | __float_as_uint(p.w)) : kKnnInvalid;
