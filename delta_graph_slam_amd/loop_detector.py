@@ -22,7 +22,7 @@ from typing import Any, List, Optional, Sequence
 
 import numpy as np
 
-from .transforms import transform2Dto3D, transform3Dto2D
+from .transforms import transform2Dto3D_batch, transform2Dto3D, transform3Dto2D
 
 try:
     import torch
@@ -122,6 +122,15 @@ class LoopDetector:
         rel = np.linalg.inv(np.asarray(new_keyframe.estimate, np.float64)) @ np.asarray(candidate.estimate, np.float64)
         return transform2Dto3D(rel.astype(np.float32))
 
+    @staticmethod
+    def guesses_for(new_keyframe: KeyFrame, candidates: Sequence[KeyFrame]) -> np.ndarray:
+        """guess_for over many candidates in one numpy pass -> [n,4,4] float32 (bit-identical to the per-candidate form)."""
+        if len(candidates) == 0:
+            return np.zeros((0, 4, 4), np.float32)
+        inv_new = np.linalg.inv(np.asarray(new_keyframe.estimate, np.float64))
+        est = np.stack([np.asarray(k.estimate, np.float64) for k in candidates])
+        return transform2Dto3D_batch((inv_new @ est).astype(np.float32))
+
     # ---------------------------------------------------------------------------------------------- sharding
     def _world(self):
         if dist is not None and dist.is_available() and dist.is_initialized():
@@ -136,17 +145,23 @@ class LoopDetector:
         self.registration.setInputTarget(self.resident(new_keyframe))
         mine = list(range(rank, n, world))
         sources = [self.resident(candidates[c]) for c in mine]
-        guesses = [self.guess_for(new_keyframe, candidates[c]) for c in mine]
-        results = self.registration.align_batch(sources, guesses, compute_fitness=True,
-                                                fitness_max_range=self.fitness_score_max_range) if mine else []
+        guesses = self.guesses_for(new_keyframe, [candidates[c] for c in mine])
         per_rank = (n + world - 1) // world
         rec = np.full((per_rank, RECORD_WIDTH), -1.0, dtype=np.float64)
-        for j, (c, r) in enumerate(zip(mine, results)):
-            rec[j, 0] = c
-            rec[j, 1] = 1.0 if r["converged"] else 0.0
-            rec[j, 2] = r["fitness"]
-            rec[j, 3] = r.get("status", 0)
-            rec[j, 4:20] = np.asarray(r["T"], np.float64).reshape(16)
+        if mine:
+            if hasattr(self.registration, "align_batch_records"):
+                # product path: the C ABI's result array goes straight into the record rows
+                rec[:len(mine)] = self.registration.align_batch_records(sources, guesses, compute_fitness=True,
+                                                                        fitness_max_range=self.fitness_score_max_range)
+                rec[:len(mine), 0] = mine
+            else:
+                results = self.registration.align_batch(sources, list(guesses), compute_fitness=True, fitness_max_range=self.fitness_score_max_range)
+                for j, (c, r) in enumerate(zip(mine, results)):
+                    rec[j, 0] = c
+                    rec[j, 1] = 1.0 if r["converged"] else 0.0
+                    rec[j, 2] = r["fitness"]
+                    rec[j, 3] = r.get("status", 0)
+                    rec[j, 4:20] = np.asarray(r["T"], np.float64).reshape(16)
         if world == 1:
             allrec = rec
         else:

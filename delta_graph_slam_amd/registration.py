@@ -56,6 +56,12 @@ def _from_col16(t16) -> np.ndarray:
     return np.array(t16, dtype=np.float32).reshape(4, 4).T.copy()
 
 
+# numpy view of dgs_result (include/dgs_reg.h)
+_RESULT_DTYPE = np.dtype([("T", np.float32, (16,)), ("converged", np.int32), ("iterations", np.int32), ("evaluations", np.int32),
+                          ("status", np.int32), ("score", np.float64), ("fitness", np.float64)])
+assert _RESULT_DTYPE.itemsize == C.sizeof(L.Result)
+
+
 class DeviceCloud:
     """A cloud resident in HBM (dgs_cloud): KeyFrame::cloud of the loop detector kept on the device together with its
     NN index / GICP covariances, so a keyframe that is a loop candidate tick after tick is uploaded and indexed once."""
@@ -232,18 +238,23 @@ class Registration:
         return out[:m.value].copy()
 
     # -- batched candidates (loop_detector.hpp:137-156) ----------------------------------------------------
-    def align_batch(self, sources, guesses=None, compute_fitness: bool = True, fitness_max_range: float = 1.7976931348623157e308):
+    def _align_batch_raw(self, sources, guesses, compute_fitness, fitness_max_range):
+        """-> ctypes array of dgs_result, one per source"""
         n = len(sources)
-        if n == 0:
-            return []
+        g = None
+        gp = None
+        if guesses is not None:
+            ga = np.asarray(guesses, dtype=np.float32)
+            if ga.ndim == 3:   # [n,4,4] row-major -> n x column-major float[16]
+                g = np.ascontiguousarray(ga.transpose(0, 2, 1).reshape(n, 16))
+            else:
+                g = np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
+            gp = g.ctypes.data_as(C.c_void_p)
+        res = (L.Result * n)()
         if all(isinstance(s_, DeviceCloud) for s_ in sources):
             cl = (C.c_void_p * n)(*[s_._c.value for s_ in sources])
-            g = None if guesses is None else np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
-            res = (L.Result * n)()
-            self._check(self._lib.dgs_align_batch_clouds(self._h, n, cl, None if g is None else g.ctypes.data_as(C.c_void_p),
-                                                          1 if compute_fitness else 0, fitness_max_range, res))
-            return [dict(T=_from_col16(r.final_transformation), converged=bool(r.converged), iterations=r.iterations,
-                         evaluations=r.evaluations, status=r.status, score=r.score, fitness=r.fitness) for r in res]
+            self._check(self._lib.dgs_align_batch_clouds(self._h, n, cl, gp, 1 if compute_fitness else 0, fitness_max_range, res))
+            return res
         ptrs = (C.c_void_p * n)()
         sizes = (C.c_int64 * n)()
         keep = []
@@ -258,16 +269,30 @@ class Registration:
         if len(devs) > 1:
             raise ValueError("sources must be all host arrays or all device tensors")
         on_device = devs.pop() if devs else 0
-        g = None
-        gp = None
-        if guesses is not None:
-            g = np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
-            gp = g.ctypes.data_as(C.c_void_p)
-        res = (L.Result * n)()
-        rc = self._lib.dgs_align_batch(self._h, n, ptrs, sizes, on_device, gp, 1 if compute_fitness else 0, fitness_max_range, res)
-        self._check(rc)
+        self._check(self._lib.dgs_align_batch(self._h, n, ptrs, sizes, on_device, gp, 1 if compute_fitness else 0, fitness_max_range, res))
+        return res
+
+    def align_batch(self, sources, guesses=None, compute_fitness: bool = True, fitness_max_range: float = 1.7976931348623157e308):
+        if len(sources) == 0:
+            return []
+        res = self._align_batch_raw(sources, guesses, compute_fitness, fitness_max_range)
         return [dict(T=_from_col16(r.final_transformation), converged=bool(r.converged), iterations=r.iterations,
                      evaluations=r.evaluations, status=r.status, score=r.score, fitness=r.fitness) for r in res]
+
+    def align_batch_records(self, sources, guesses=None, compute_fitness: bool = True, fitness_max_range: float = 1.7976931348623157e308):
+        """align_batch as the loop detector's exchange records: float64 [n, 20] = (-1, converged, fitness, status, T row-major),
+        filled from the C ABI's result array in one numpy pass (column 0 is left for the caller's candidate index)."""
+        n = len(sources)
+        out = np.full((n, 20), -1.0, dtype=np.float64)
+        if n == 0:
+            return out
+        res = self._align_batch_raw(sources, guesses, compute_fitness, fitness_max_range)
+        a = np.frombuffer(res, dtype=_RESULT_DTYPE, count=n)
+        out[:, 1] = a["converged"] != 0
+        out[:, 2] = a["fitness"]
+        out[:, 3] = a["status"]
+        out[:, 4:20] = a["T"].reshape(n, 4, 4).transpose(0, 2, 1).reshape(n, 16)   # column-major -> row-major
+        return out
 
     # -- measurement / test hooks ---------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

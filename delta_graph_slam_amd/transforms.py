@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["transform2Dto3D", "transform3Dto2D", "euler_angles_012", "normalize_euler_angs"]
+__all__ = ["transform2Dto3D", "transform2Dto3D_batch", "transform3Dto2D", "euler_angles_012", "normalize_euler_angs"]
 
 
 def euler_angles_012(R) -> np.ndarray:
@@ -41,6 +41,19 @@ def transform2Dto3D(trans2D) -> np.ndarray:
     T = np.eye(4, dtype=np.float32)
     T[0, 0], T[0, 1], T[1, 0], T[1, 1] = c, -s, s, c
     T[0, 3], T[1, 3] = t[0, 2], t[1, 2]
+    return T
+
+
+def transform2Dto3D_batch(trans2D) -> np.ndarray:
+    """transform2Dto3D over a stack [n,3,3] -> [n,4,4] float32 (same arithmetic, one numpy pass)."""
+    t = np.asarray(trans2D, dtype=np.float32)
+    ang = np.arctan2(t[:, 1, 0], t[:, 0, 0]).astype(np.float32)
+    c, s = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+    T = np.zeros((t.shape[0], 4, 4), dtype=np.float32)
+    T[:, 0, 0], T[:, 0, 1], T[:, 1, 0], T[:, 1, 1] = c, -s, s, c
+    T[:, 2, 2] = 1.0
+    T[:, 3, 3] = 1.0
+    T[:, 0, 3], T[:, 1, 3] = t[:, 0, 2], t[:, 1, 2]
     return T
 
 
