@@ -108,3 +108,56 @@ def test_odometry_driver_sequence_on_cpu_engine():
     # 0.3 m per frame against keyframe_delta_trans 0.5: the keyframe is replaced after frames 2 and 4
     assert odo.n_keyframes == 3
     assert np.array_equal(odo.prev_trans, np.eye(4, dtype=np.float32))            # reset at the last switch (:259)
+
+
+def test_batched_guesses_equal_the_per_candidate_form():
+    from delta_graph_slam_amd.loop_detector import KeyFrame, LoopDetector
+    rng = np.random.default_rng(3)
+
+    def se2():
+        a = rng.uniform(-np.pi, np.pi)
+        return np.array([[np.cos(a), -np.sin(a), rng.uniform(-30, 30)], [np.sin(a), np.cos(a), rng.uniform(-30, 30)], [0, 0, 1.0]])
+    new = KeyFrame(None, se2(), 50.0, 0)
+    cands = [KeyFrame(None, se2(), 0.0, i) for i in range(17)]
+    one_by_one = np.stack([LoopDetector.guess_for(new, k) for k in cands])
+    assert np.array_equal(LoopDetector.guesses_for(new, cands), one_by_one)
+    assert LoopDetector.guesses_for(new, []).shape == (0, 4, 4)
+
+
+def test_record_path_equals_dict_path():
+    """register_shard fills its exchange records either from align_batch's dicts or from align_batch_records (the product
+    path, straight from the C ABI result array): same rows either way."""
+    from delta_graph_slam_amd.loop_detector import RECORD_WIDTH, KeyFrame, LoopDetector
+    rng = np.random.default_rng(5)
+    n = 5
+    Ts = rng.normal(size=(n, 4, 4)).astype(np.float32)
+    fits = rng.uniform(0.1, 1.0, n)
+    conv = [True, False, True, True, False]
+
+    class DictEngine:
+        def setInputTarget(self, cloud):
+            pass
+
+        def align_batch(self, sources, guesses=None, compute_fitness=True, fitness_max_range=0.0):
+            self.guesses = np.asarray(guesses)
+            return [dict(T=Ts[i], converged=conv[i], iterations=1, evaluations=2, status=0 if conv[i] else 4, score=0.0, fitness=fits[i])
+                    for i in range(len(sources))]
+
+    class RecordEngine(DictEngine):
+        def align_batch_records(self, sources, guesses=None, compute_fitness=True, fitness_max_range=0.0):
+            self.guesses = np.asarray(guesses)
+            out = np.full((len(sources), RECORD_WIDTH), -1.0)
+            out[:, 1] = conv
+            out[:, 2] = fits
+            out[:, 3] = [0 if c else 4 for c in conv]
+            out[:, 4:20] = Ts.astype(np.float64).reshape(n, 16)
+            return out
+
+    new = KeyFrame(np.zeros((1, 4), np.float32), np.eye(3), 50.0, 0)
+    cands = [KeyFrame(np.zeros((1, 4), np.float32), np.eye(3), 0.0, i) for i in range(n)]
+    a, b = DictEngine(), RecordEngine()
+    ra = LoopDetector({}, registration=a).register_shard(cands, new)
+    rb = LoopDetector({}, registration=b).register_shard(cands, new)
+    assert np.array_equal(ra, rb) and np.array_equal(a.guesses, b.guesses)
+    assert list(ra[:, 0]) == list(range(n))
+    assert LoopDetector.select_best(ra)[0] == LoopDetector.select_best(rb)[0]

@@ -107,3 +107,19 @@ def test_batch_results_do_not_depend_on_candidate_order(scans, method):
     c = r.align_batch(sources, guesses)
     for x, y in zip(a, c):
         assert np.array_equal(x["T"], y["T"]) and x["fitness"] == y["fitness"]
+
+
+def test_records_api_equals_dict_api(scans):
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, _ = scans
+    r = Registration("NDT_OMP")
+    r.setInputTarget(tgt)
+    srcs = sources[:3] + [np.zeros((0, 4), np.float32)]
+    gs = np.stack(list(guesses[:3]) + [np.eye(4, dtype=np.float32)])
+    d = r.align_batch(srcs, list(gs))
+    rec = r.align_batch_records(srcs, gs)
+    assert rec.shape == (4, 20)
+    for k in range(4):
+        assert rec[k, 1] == float(d[k]["converged"]) and rec[k, 3] == d[k]["status"]
+        assert np.array_equal(rec[k, 4:20].reshape(4, 4).astype(np.float32), d[k]["T"])
+        assert rec[k, 2] == d[k]["fitness"] or (np.isnan(rec[k, 2]) and np.isnan(d[k]["fitness"]))
