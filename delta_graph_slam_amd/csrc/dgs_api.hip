@@ -28,6 +28,12 @@ int ensure_pinned(dgs_handle* h, size_t bytes) {
   return DGS_OK;
 }
 
+int ensure_poll_events(dgs_handle* h) {
+  for (int k = 0; k < 2; k++)
+    if (!h->ev_poll[k]) DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_poll[k], hipEventDisableTiming));
+  return DGS_OK;
+}
+
 int prof_begin(dgs_handle* h, int kernel_id) {
   Profiler& p = h->prof;
   if (!p.enabled) return -1;
@@ -190,6 +196,9 @@ void dgs_destroy(dgs_handle* h) {
   unbind(h, h->tgt_cloud);
   unbind(h, h->src_cloud);
   h->own_target.release(); h->own_source.release();
+  for (int k = 0; k < 2; k++)
+    if (h->ev_poll[k]) (void)hipEventDestroy(h->ev_poll[k]);
+  h->batch_slab.release();
   for (auto& c : h->batch_clouds) c.release();
   h->gitems.release(); h->vvox.release(); h->vcell2vox.release();
   h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
@@ -493,10 +502,10 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
     }
     return gicp_batch(h, n, cs.data(), guesses16, compute_fitness, fitness_max_range, results);
   }
-  // stage sources on the device when they come from the host (one contiguous slab)
+  // stage sources on the device when they come from the host (one contiguous slab, kept by the handle between calls)
   std::vector<const float4*> ptrs(n);
   std::vector<int> sz(n);
-  DevBuf<float4> slab;
+  DevBuf<float4>& slab = h->batch_slab;
   int64_t total = 0;
   for (int i = 0; i < n; i++) {
     if (sizes[i] < 0 || sizes[i] > INT32_MAX || (sizes[i] > 0 && !sources[i])) return DGS_ERR_INVALID_ARGUMENT;
@@ -533,7 +542,6 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
         fail_result(&results[i], guesses16 ? guesses16 + 16 * i : nullptr, DGS_ERR_NO_SOURCE);
   }
   (void)hipStreamSynchronize(h->stream);
-  slab.release();
   return rc;
 }
 

@@ -774,9 +774,8 @@ int gicp_align_batch(dgs_handle* h, int n, CloudState* const* srcs, const float*
   if (n_live > 0) {
     volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);
     flags[0] = flags[1] = 0;
-    hipEvent_t ev[2];
-    DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    if (ensure_poll_events(h) != DGS_OK) return DGS_ERR_HIP;
+    hipEvent_t* ev = h->ev_poll;
     const long max_rounds = (long)h->prm.maximum_iterations * (h->prm.gicp_lm_max_iterations + 1) + 4;
     const int chunk = 4;
     long queued = 0;
@@ -799,8 +798,6 @@ int gicp_align_batch(dgs_handle* h, int n, CloudState* const* srcs, const float*
       if (!more) break;
       cur ^= 1;
     }
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
     if (rc != DGS_OK) return rc;
   }
   GicpPair* hp = gicp_read_back(h, n, &rc);

@@ -64,6 +64,7 @@ struct dgs_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipEvent_t ev_poll[2] = {nullptr, nullptr};  // chunk-boundary events of the optimiser loops (created on first use)
   std::string err;
 
   // clouds (pcl::PointXYZ layout): the handle's own copies, or borrowed dgs_cloud objects
@@ -131,6 +132,7 @@ struct dgs_handle {
   dgs::DevBuf<int> vcell2vox;
   bool vmap_valid = false;
   int64_t vmap_voxels = 0;
+  dgs::DevBuf<float4> batch_slab;              // host sources of dgs_align_batch staged as one slab (kept across calls)
   std::vector<dgs::CloudState> batch_clouds;   // index + covariances of sources handed to dgs_align_batch as raw arrays
   dgs::GicpConsts gconsts{};
 
@@ -143,6 +145,7 @@ namespace dgs {
 int prof_begin(dgs_handle* h, int kernel_id);
 void prof_end(dgs_handle* h, int kernel_id, int slot);
 int ensure_pinned(dgs_handle* h, size_t bytes);
+int ensure_poll_events(dgs_handle* h);
 
 // ndt_voxel.hip
 int ndt_build_target(dgs_handle* h);

@@ -798,9 +798,8 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   // ---- iterate: chunks of (derivatives, solve) launches; the host looks at the done counter one chunk behind
   volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);  // [0], [1]: done counts of alternating chunks
   flags[0] = flags[1] = 0;
-  hipEvent_t ev[2];
-  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-  DGS_HIP_TRY(h, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+  if (ensure_poll_events(h) != DGS_OK) return DGS_ERR_HIP;
+  hipEvent_t* ev = h->ev_poll;
   const int per_iter = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
   const long max_evals = (long)(h->prm.maximum_iterations + 3) * per_iter + 2;
   const int chunk = 4;  // (derivatives, solve) launches between two looks at the done counter
@@ -828,8 +827,6 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
     if (!more) break;
     cur ^= 1;
   }
-  (void)hipEventDestroy(ev[0]);
-  (void)hipEventDestroy(ev[1]);
   if (rc != DGS_OK) return rc;
   (void)finished;  // pairs that did not finish inside max_evals export converged = 0
 
