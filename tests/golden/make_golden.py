@@ -62,5 +62,29 @@ def main():
     print("wrote", os.path.join(HERE, "registration_small.npz"))
 
 
+def main_vgicp():
+    """FAST_VGICP self-goldens, kept in their own file so that the first file never needs regenerating."""
+    tgt, src, Tgt = synth.planar_pair(n=2048, seed_target=101, seed_source=102)
+    out = dict(tgt=tgt, src=src, T_gt=Tgt)
+    T1 = synth.make_transform((0.12, -0.07, 0.03), (0.01, -0.02, 0.03))
+    for search in ("DIRECT1", "DIRECT7", "DIRECT27"):
+        o = orc.VgicpOracle(resolution=1.0, search_method=search)
+        o.set_target(tgt)
+        o.set_source(src)
+        if search == "DIRECT1":
+            coords, counts, means, covs = o.voxels()
+            out["vox_coords"], out["vox_counts"], out["vox_means"], out["vox_covs"] = coords, counts, means, covs
+        e, H, b = o.linearize(T1)
+        out[f"{search}_lin_err"], out[f"{search}_lin_H"], out[f"{search}_lin_b"] = e, H, b
+        r = o.align()
+        out[f"{search}_T"] = r["T"]
+        out[f"{search}_iters"] = np.array([r["iterations"], r["evaluations"], int(r["converged"])])
+    out["T1"] = T1
+    np.savez_compressed(os.path.join(HERE, "vgicp_small.npz"), **out)
+    print("wrote", os.path.join(HERE, "vgicp_small.npz"))
+
+
 if __name__ == "__main__":
-    main()
+    if "--vgicp-only" not in sys.argv:
+        main()
+    main_vgicp()

@@ -121,3 +121,22 @@ def test_set_target_rebuilds_the_voxelmap(oracle_lib, pair):
     n1 = o.voxels()[1].sum()
     o.set_target(tgt[:1000])
     assert o.voxels()[1].sum() == 1000 and n1 == tgt.shape[0]
+
+
+def test_matches_committed_goldens(oracle_lib):
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgicp_small.npz"))
+    for search in ("DIRECT1", "DIRECT7", "DIRECT27"):
+        o = oracle_lib.VgicpOracle(resolution=1.0, search_method=search)
+        o.set_target(G["tgt"])
+        o.set_source(G["src"])
+        if search == "DIRECT1":
+            coords, counts, means, covs = o.voxels()
+            assert np.array_equal(coords, G["vox_coords"]) and np.array_equal(counts, G["vox_counts"])
+            assert np.allclose(means, G["vox_means"], rtol=0, atol=1e-12) and np.allclose(covs, G["vox_covs"], rtol=1e-10, atol=1e-14)
+        e, H, b = o.linearize(G["T1"])
+        assert abs(e - float(G[f"{search}_lin_err"])) <= 1e-10 * abs(e)
+        assert np.allclose(H, G[f"{search}_lin_H"], rtol=1e-10, atol=1e-9) and np.allclose(b, G[f"{search}_lin_b"], rtol=1e-10, atol=1e-9)
+        r = o.align()
+        assert [r["iterations"], r["evaluations"], int(r["converged"])] == list(G[f"{search}_iters"])
+        assert np.allclose(r["T"], G[f"{search}_T"], rtol=0, atol=2e-6)

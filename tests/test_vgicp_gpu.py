@@ -121,3 +121,25 @@ def test_factory_selects_vgicp():
     assert reg.hasConverged()
     dt, dr = pose_error(reg.getFinalTransformation(), Tgt)
     assert dt < 0.01 and dr < 1e-3
+
+
+def test_committed_goldens_on_the_device():
+    import os
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd.registration import Registration
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "vgicp_small.npz"))
+    for search in ("DIRECT1", "DIRECT7", "DIRECT27"):
+        r = Registration("FAST_VGICP", vgicp_resolution=1.0, vgicp_search_method=L.VGICP_SEARCH[search])
+        r.setInputTarget(G["tgt"])
+        r.setInputSource(G["src"])
+        if search == "DIRECT1":
+            coords, counts, means, covs = r.vgicp_voxels()
+            assert np.array_equal(coords, G["vox_coords"]) and np.array_equal(counts, G["vox_counts"])
+            assert np.array_equal(means, G["vox_means"])
+        e, H, b = r.gicp_linearize(G["T1"])
+        assert abs(e - float(G[f"{search}_lin_err"])) <= 1e-8 * abs(e)
+        assert np.abs(H - G[f"{search}_lin_H"]).max() <= 1e-8 * np.abs(H).max()
+        r.align()
+        assert [r.last_result.iterations, r.last_result.evaluations, int(r.hasConverged())] == list(G[f"{search}_iters"])
+        dt, dr = pose_error(r.getFinalTransformation(), G[f"{search}_T"])
+        assert dt <= 1e-6 and dr <= 1e-7
