@@ -285,45 +285,47 @@ __device__ __forceinline__ unsigned long long knn_largest(const KnnList& L) {
 }
 
 // All 8 lanes of the group end with the same distributed set.  `alive` = false lanes follow the control flow only.
-__device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L) {
+// Same instruction-lean loop as nn_query_group_t (32-bit pending word for trees of up to 5 levels, FLT_MAX instead of +inf as
+// the open bound so that one compare rejects the inverted boxes of empty slots).
+template <class PT>
+__device__ __forceinline__ void knn_query_group_t(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L) {
   const int lane = threadIdx.x & 63;
-  const int sub = lane & 7, gshift = lane & ~7;
+  const unsigned sub = lane & 7, gshift = lane & ~7, bit = 1u << sub;
 #pragma unroll
   for (int r = 0; r < kKnnSlots; r++) {
-    const int slot = r * 8 + sub;
+    const int slot = r * 8 + (int)sub;
     L.key[r] = (slot < k) ? (((unsigned long long)__float_as_uint(INFINITY) << 32) | (unsigned)(0x7FFFFFFF - slot)) : 0ull;
   }
   unsigned long long worst = knn_largest(L);
-  float td = INFINITY;  // distance part of `worst`: boxes farther than this cannot hold a better point
+  float td = FLT_MAX;  // min(distance part of `worst`, FLT_MAX): boxes farther than this cannot hold a better point
   int node = 0, sh = 0;
   const int last_sh = 8 * (b.depth - 1);
-  unsigned long long pend = 0ull;
+  PT pend = 0;
   bool fresh = true;
   bool done = !alive;
   while (__any(!done)) {
     if (!done) {
-      const unsigned ofs = (unsigned)node * kFan + (unsigned)sub;
+      const unsigned ofs = (unsigned)node * kFan + sub;
       const float4 lo = load16_at(b.box_lo, ofs), hi = load16_at(b.box_hi, ofs);
       const float d = aabb_sqdist_rn(lo, hi, x, y, z);
-      unsigned mask = (unsigned)((__ballot(d <= td && d < INFINITY) >> gshift) & 0xFFull);
+      unsigned mask = (unsigned)(__ballot(d <= td) >> gshift) & 0xFFu;
       if (!fresh) {
-        mask &= (unsigned)((pend >> sh) & 0xFFull);
-        pend &= ~(0xFFull << sh);
+        mask &= (unsigned)(pend >> sh) & 0xFFu;
+        pend &= ~((PT)0xFFu << sh);
       }
-      const bool last = (sh == last_sh);
-      if (last) {
+      if (sh == last_sh) {
         while (mask) {
-          const unsigned bkey = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-          const int c = (int)(group8_min_u32(bkey) & 7u);
+          const unsigned bkey = (mask & bit) ? ((__float_as_uint(d) & ~7u) | sub) : 0xFFFFFFFFu;
+          const unsigned c = group8_min_u32(bkey) & 7u;
           mask &= ~(1u << c);
-          const unsigned leaf = (unsigned)((node * kFan + 1 + c) - b.first_leaf);
-          const float4 p = load16_at(b.sorted, leaf * kLeaf + (unsigned)sub);
+          const unsigned leaf = ((unsigned)node * kFan + 1u + c) - (unsigned)b.first_leaf;
+          const float4 p = load16_at(b.sorted, leaf * kLeaf + sub);
           const float dp = sqdist_rn(x, y, z, p.x, p.y, p.z);
           // this lane's point as a candidate key; padding / non-finite points never qualify
           unsigned long long cand = (dp < INFINITY) ? (((unsigned long long)__float_as_uint(dp) << 32) | __float_as_uint(p.w)) : kKnnInvalid;
           if (!(cand < worst)) cand = kKnnInvalid;
           // take the leaf's candidates smallest first: each one that gets in lowers the bar for the rest
-          while (__ballot(cand != kKnnInvalid) >> gshift & 0xFFull) {
+          while ((unsigned)(__ballot(cand != kKnnInvalid) >> gshift) & 0xFFu) {
             const unsigned long long best = group8_min_u64(cand);
 #pragma unroll
             for (int r = 0; r < kKnnSlots; r++)
@@ -331,25 +333,31 @@ __device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float
             worst = knn_largest(L);
             if (cand == best || !(cand < worst)) cand = kKnnInvalid;
           }
-          td = __uint_as_float((unsigned)(worst >> 32));
-          mask &= (unsigned)((__ballot(d <= td) >> gshift) & 0xFFull);
+          td = fminf(__uint_as_float((unsigned)(worst >> 32)), FLT_MAX);
+          mask &= (unsigned)(__ballot(d <= td) >> gshift) & 0xFFu;
         }
         fresh = false;
-        if (!nn_pop<unsigned long long>(pend, node, sh)) done = true;
+        if (!nn_pop<PT>(pend, node, sh)) done = true;
       } else if (mask) {
-        const unsigned bkey = ((mask >> sub) & 1u) ? ((__float_as_uint(d) & ~7u) | (unsigned)sub) : 0xFFFFFFFFu;
-        const int c = (int)(group8_min_u32(bkey) & 7u);
-        mask &= ~(1u << c);
-        pend |= (unsigned long long)mask << sh;
-        node = node * kFan + 1 + c;
+        const unsigned bkey = (mask & bit) ? ((__float_as_uint(d) & ~7u) | sub) : 0xFFFFFFFFu;
+        const unsigned c = group8_min_u32(bkey) & 7u;
+        pend |= (PT)(mask & ~(1u << c)) << sh;
+        node = node * kFan + 1 + (int)c;
         sh += 8;
         fresh = true;
       } else {
         fresh = false;
-        if (!nn_pop<unsigned long long>(pend, node, sh)) done = true;
+        if (!nn_pop<PT>(pend, node, sh)) done = true;
       }
     }
   }
+}
+
+__device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L) {
+  if (b.depth <= 5)
+    knn_query_group_t<unsigned>(b, x, y, z, alive, k, L);
+  else
+    knn_query_group_t<unsigned long long>(b, x, y, z, alive, k, L);
 }
 
 // host: device view of a built index (nn_bvh.hip)

@@ -336,7 +336,8 @@ class Registration:
         return s.value, g, H
 
     def gicp_covariances(self, which: str = "source", n: int | None = None):
-        n = self._n_source if (which == "source" and n is None) else n
+        c = self.counts()   # the library writes one 3x3 per point of the cloud it holds: size the buffer from ITS count
+        n = int(c["source_points"] if which == "source" else c["target_points"])
         out = np.zeros((n, 3, 3))
         self._check(self._lib.dgs_gicp_get_covariances(self._h, 0 if which == "source" else 1, out.ctypes.data_as(C.c_void_p)))
         return out
