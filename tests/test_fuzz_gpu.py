@@ -1,0 +1,135 @@
+"""-m gpu randomized parity sweep: many small seeded scenes with awkward shapes (odd sizes, offsets far from the origin,
+duplicate and non-finite points, thin and tiny clouds, random resolutions / search methods / guesses).  Asserted per case:
+NDT derivatives vs the oracle (the per-evaluation tier of DESIGN.md "NDT sensitivity"), GICP / VGICP linearisation vs the
+oracle, and exactness of the fitness score against a kd-tree.  Final poses are compared where the optimiser is well
+conditioned (double-precision GICP / VGICP)."""
+import numpy as np
+import pytest
+
+from delta_graph_slam_amd import synth
+from tests.helpers import f32_sqdist, f32_transform, pose_error
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rng, n):
+    """A few random planes + a blob, random offset, float32 [n,4]."""
+    parts = []
+    k = int(rng.integers(2, 5))
+    for _ in range(k):
+        m = n // (k + 1)
+        o = rng.uniform(-8, 8, 3)
+        u, v = rng.normal(size=3), rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        v -= u * (u @ v)
+        v /= np.linalg.norm(v)
+        a, b = rng.uniform(-6, 6, (2, m))
+        parts.append(o + a[:, None] * u + b[:, None] * v + rng.normal(0, 0.02, (m, 3)))
+    parts.append(rng.normal(0, 2.0, (n - sum(p.shape[0] for p in parts), 3)))
+    xyz = np.concatenate(parts) + rng.uniform(-200, 200, 3) * (rng.random() < 0.5)
+    out = np.ones((n, 4), np.float32)
+    out[:, :3] = xyz[rng.permutation(n)]
+    return out
+
+
+def _cases(count, seed):
+    rng = np.random.default_rng(seed)
+    for c in range(count):
+        n = int(rng.choice([257, 640, 1500, 4099, 9000]))
+        tgt = _scene(rng, n)
+        T = synth.make_transform(rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.04, 0.04, 3))
+        m = int(rng.integers(n // 3, n))
+        src = np.ones((m, 4), np.float32)
+        sel = rng.permutation(n)[:m]
+        src[:, :3] = (tgt[sel, :3].astype(np.float64) - T[:3, 3]) @ T[:3, :3] + rng.normal(0, 0.01, (m, 3))
+        if rng.random() < 0.4:   # duplicates
+            src[: m // 10] = src[m // 10: 2 * (m // 10)]
+        yield c, rng, tgt, src, T
+
+
+def test_ndt_derivatives_sweep(oracle_lib):
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd.registration import Registration
+    worst = 0.0
+    for c, rng, tgt, src, T in _cases(48, 11):
+        res = float(rng.choice([0.5, 0.8, 1.0, 1.7, 2.0]))
+        search = str(rng.choice(["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"]))
+        tgt = tgt.copy()
+        if c % 4 == 0:           # non-finite target points are skipped by the voxel filter
+            tgt[3, 0] = np.nan
+            tgt[5, 1] = np.inf
+        clean = tgt[np.isfinite(tgt).all(1)]
+        o = oracle_lib.NdtOracle(resolution=res, search_method=search)
+        o.set_target(clean)
+        o.set_source(src)
+        r = Registration("NDT_OMP", ndt_resolution=res, ndt_search_method=L.NDT_SEARCH[search])
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        for _ in range(2):
+            p = np.concatenate([T[:3, 3] + rng.uniform(-0.2, 0.2, 3), rng.uniform(-0.05, 0.05, 3)])
+            so, go, Ho = o.derivatives(p)
+            sg, gg, Hg = r.ndt_derivatives(p)
+            scale_g, scale_h = np.abs(go).max() + 1e-12, np.abs(Ho).max() + 1e-12
+            assert abs(so - sg) <= 2e-6 * abs(so) + 1e-9, (c, res, search)
+            assert np.abs(go - gg).max() <= 2e-5 * scale_g + 1e-7, (c, res, search, np.abs(go - gg).max() / scale_g)
+            assert np.abs(Ho - Hg).max() <= 2e-5 * scale_h + 1e-6, (c, res, search, np.abs(Ho - Hg).max() / scale_h)
+            worst = max(worst, np.abs(go - gg).max() / scale_g)
+        # the align itself must terminate and report a transform near the truth or not converged -- never garbage
+        r.align(T.astype(np.float32))
+        assert np.isfinite(r.getFinalTransformation()).all()
+    assert worst < 2e-5
+
+
+@pytest.mark.parametrize("method", ["FAST_GICP", "FAST_VGICP"])
+def test_gicp_family_sweep(oracle_lib, method):
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd.registration import Registration
+    for c, rng, tgt, src, T in _cases(24, 23):
+        k = int(rng.choice([5, 10, 20]))
+        if method == "FAST_GICP":
+            dmax = float(rng.choice([0.5, 1.0, 2.5]))
+            o = oracle_lib.GicpOracle(max_correspondence_distance=dmax, k_correspondences=k)
+            r = Registration(method, gicp_max_correspondence_distance=dmax, gicp_correspondence_randomness=k)
+        else:
+            res = float(rng.choice([0.6, 1.0, 1.5]))
+            search = str(rng.choice(["DIRECT1", "DIRECT7", "DIRECT27"]))
+            o = oracle_lib.VgicpOracle(resolution=res, search_method=search, k_correspondences=k)
+            r = Registration(method, vgicp_resolution=res, vgicp_search_method=L.VGICP_SEARCH[search], gicp_correspondence_randomness=k)
+        o.set_target(tgt)
+        o.set_source(src)
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        Tp = synth.make_transform(T[:3, 3] + rng.uniform(-0.1, 0.1, 3), rng.uniform(-0.02, 0.02, 3))
+        Tp[:3, :3] = Tp[:3, :3] @ T[:3, :3]
+        eo, Ho, bo = o.linearize(Tp)
+        eg, Hg, bg = r.gicp_linearize(Tp)
+        # exact k-NN on both sides; a tie at the k-th neighbour may swap one member of one covariance (duplicated points make
+        # ties common), so the sums agree to ~1e-5 rather than to rounding
+        tol = 2e-4
+        assert abs(eo - eg) <= tol * abs(eo) + 1e-9, (c, abs(eo - eg) / abs(eo))
+        assert np.abs(Ho - Hg).max() <= tol * np.abs(Ho).max(), c
+        ro = o.align(T.astype(np.float32))
+        r.align(T.astype(np.float32))
+        assert r.hasConverged() == ro["converged"], c
+        dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+        assert dt <= 2e-4 and dr <= 2e-5, (c, dt, dr)
+
+
+def test_fitness_sweep_is_exact():
+    from scipy.spatial import cKDTree
+    from delta_graph_slam_amd.registration import Registration
+    r = Registration("NDT_OMP")
+    for c, rng, tgt, src, T in _cases(16, 37):
+        tgt = tgt.copy()
+        tgt[::97, 0] = np.nan                           # holes in the target
+        clean = tgt[np.isfinite(tgt).all(1)]
+        G = (T @ synth.make_transform(rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.1, 0.1, 3))).astype(np.float32)
+        xt = f32_transform(G, src)
+        _, nn = cKDTree(clean[:, :3].astype(np.float64)).query(xt.astype(np.float64), k=1)
+        d2 = f32_sqdist(xt, clean[nn, :3])
+        for mr in (1.7976931348623157e308, 0.25):
+            got = r.calc_fitness_score(tgt, src, G, mr) if hasattr(r, "calc_fitness_score") else None
+            sel = d2 <= np.float32(min(mr, 3.4e38))
+            want = float(np.mean(d2[sel].astype(np.float64))) if sel.any() else 1.7976931348623157e308
+            # the device may find an equally near or nearer point on float ties, never a farther one
+            assert got <= want * (1 + 1e-12) and got >= want * (1 - 1e-6), (c, mr, got, want)
