@@ -222,3 +222,32 @@ def test_edge_cases_on_the_device():
         r2 = _reg(ndt_resolution=0.01)
         r2.setInputTarget(huge)                 # "Leaf size is too small for the input dataset"
     assert e.value.status == 5
+
+
+@pytest.mark.parametrize("method", ["FAST_GICP", "FAST_VGICP"])
+def test_cfg2_kitti_pair_gicp_family(oracle_lib, method):
+    """configs[1]'s 65,536-point pair through the two GICP back-ends: same iterations and the same pose as the restatement."""
+    tgt, src, Tgt = synth.kitti_pair()
+    guess = Tgt.copy()
+    guess[0, 3] -= 0.25
+    guess[1, 3] += 0.10
+    guess = guess.astype(np.float32)
+    if method == "FAST_GICP":
+        o = oracle_lib.GicpOracle(max_correspondence_distance=2.5)
+        r = _reg(method, gicp_max_correspondence_distance=2.5)
+    else:
+        o = oracle_lib.VgicpOracle(resolution=1.0)
+        r = _reg(method, vgicp_resolution=1.0)
+    o.set_target(tgt)
+    o.set_source(src)
+    ro = o.align(guess)
+    r.setInputTarget(tgt)
+    r.setInputSource(src)
+    r.align(guess)
+    assert r.hasConverged() == ro["converged"]
+    assert r.last_result.iterations == ro["iterations"] and r.last_result.evaluations == ro["evaluations"]
+    et, er = pose_error(r.getFinalTransformation(), ro["T"])
+    assert et <= 1e-6 and er <= 1e-7, (et, er)          # double-precision optimiser: far inside the 1e-4 m / 1e-5 rad gate
+    assert pose_error(r.getFinalTransformation(), Tgt)[0] < 0.05
+    fo, _, _ = oracle_lib.fitness_score(tgt, src, r.getFinalTransformation())
+    assert abs(r.getFitnessScore() - fo) <= 1e-11 * fo
