@@ -65,6 +65,10 @@ struct dgs_handle {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_poll[2] = {nullptr, nullptr};  // chunk-boundary events of the optimiser loops (created on first use)
+  // side stream: small builds that the main stream does not need yet (the target's NN index while the batch iterates)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_pending = false;
   std::string err;
 
   // clouds (pcl::PointXYZ layout): the handle's own copies, or borrowed dgs_cloud objects
@@ -146,19 +150,21 @@ int prof_begin(dgs_handle* h, int kernel_id);
 void prof_end(dgs_handle* h, int kernel_id, int slot);
 int ensure_pinned(dgs_handle* h, size_t bytes);
 int ensure_poll_events(dgs_handle* h);
+int side_fork(dgs_handle* h);   // side_stream continues from what the main stream has enqueued so far
+int side_join(dgs_handle* h);   // the main stream waits for what side_fork()'s work (no-op when nothing is pending)
 
 // ndt_voxel.hip
 int ndt_build_target(dgs_handle* h);
 int voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, float4* out, int64_t out_capacity, int64_t* n_out);
 int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]);
-int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6);
+int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6, hipStream_t st = nullptr);
 // ndt_align.hip
 int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs_host, const int* sizes_host,
                     const float* guesses16, dgs_result* results);
 int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len);
 int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36);
 // nn_bvh.hip
-int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n);
+int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n, hipStream_t st = nullptr);  // st: default the handle's stream
 int nn_fitness(dgs_handle* h, const float4* src, int64_t n, const float* T16, double max_range, double inlier_sq,
                double* sum, int64_t* count, int64_t* inliers);
 // batched: device arrays of source pointers / sizes, device transforms (column-major 16 floats every T_stride_bytes)

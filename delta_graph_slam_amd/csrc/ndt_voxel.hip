@@ -67,8 +67,8 @@ __global__ void minmax_final_kernel(const float* __restrict__ partial, int nbloc
 }
 
 // AABB of the finite points of a device cloud, left on the device (6 floats: min xyz, max xyz); no synchronisation.
-int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6) {
-  hipStream_t st = h->stream;
+int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6, hipStream_t stream) {
+  hipStream_t st = stream ? stream : h->stream;
   const int mm_blocks = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, 256);
   DGS_HIP_TRY(h, h->minmax_partial.reserve((size_t)512 * 6 + 8));
   float* d_final = h->minmax_partial.ptr + (size_t)512 * 6;

@@ -190,14 +190,14 @@ __global__ __launch_bounds__(kWave) void nn_fitness_final_kernel(const double* _
 }
 
 // ---- host drivers ----------------------------------------------------------------------------------------------
-int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64) {
-  hipStream_t st = h->stream;
+int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64, hipStream_t stream) {
+  hipStream_t st = stream ? stream : h->stream;
   const int n = (int)n64;
   bvh.valid = false;
   bvh.n = n;
   if (n == 0) return DGS_OK;
   float* d_mm = nullptr;
-  int rc = cloud_minmax_device(h, pts, n, &d_mm);
+  int rc = cloud_minmax_device(h, pts, n, &d_mm, st);
   if (rc) return rc;
   const int n_leaves = (n + kLeaf - 1) / kLeaf;
   int depth = 1;
@@ -250,6 +250,7 @@ BvhView make_bvh_view(const Bvh& b) {
 }
 
 static int ensure_target_bvh(dgs_handle* h) {
+  if (side_join(h) != DGS_OK) return DGS_ERR_HIP;  // an index being built on the side stream
   if (h->tgt->bvh.valid) return DGS_OK;
   return bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt);
 }
