@@ -123,3 +123,32 @@ def test_records_api_equals_dict_api(scans):
         assert rec[k, 1] == float(d[k]["converged"]) and rec[k, 3] == d[k]["status"]
         assert np.array_equal(rec[k, 4:20].reshape(4, 4).astype(np.float32), d[k]["T"])
         assert rec[k, 2] == d[k]["fitness"] or (np.isnan(rec[k, 2]) and np.isnan(d[k]["fitness"]))
+
+
+@pytest.mark.parametrize("method", ["NDT_OMP", "FAST_GICP", "FAST_VGICP"])
+def test_very_wide_batch(method):
+    """1,200 small candidates in one call (more pairs than workgroups per launch): every pair still gets served and agrees
+    with a one-by-one align of the same inputs."""
+    from delta_graph_slam_amd.registration import Registration
+    tgt, src, _ = synth.planar_pair(n=2048)
+    rng = np.random.default_rng(9)
+    n = 1200
+    sources, guesses = [], []
+    for k in range(n):
+        m = int(rng.integers(400, 2048))
+        sources.append(src[:m])
+        guesses.append(synth.make_transform(rng.uniform(-0.1, 0.1, 3), rng.uniform(-0.02, 0.02, 3)).astype(np.float32))
+    r = Registration(method)
+    r.setInputTarget(tgt)
+    res = r.align_batch_records(sources, np.stack(guesses))
+    assert res.shape == (n, 20) and np.isfinite(res[:, 4:20]).all()
+    assert (res[:, 1] > 0.5).mean() > 0.95
+    single = Registration(method)
+    single.setInputTarget(tgt)
+    for k in (0, 1, 599, 1023, 1024, 1199):
+        single.setInputSource(sources[k])
+        single.align(guesses[k])
+        dt, dr = pose_error(res[k, 4:20].reshape(4, 4), single.getFinalTransformation())
+        assert bool(res[k, 1] > 0.5) == single.hasConverged()
+        assert dt <= 1e-5 and dr <= 1e-6, (method, k, dt, dr)
+        assert abs(res[k, 2] - single.getFitnessScore()) <= 1e-6 * abs(res[k, 2])
