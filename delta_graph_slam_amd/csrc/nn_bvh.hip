@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void nn_fitness_kernel(const BvhView b, con
     const float z = affine_row_rn(t20, t21, t22, t23, p.x, p.y, p.z);
     float best;
     int bi;
-    nn_query_group(b, x, y, z, alive, nn_warm_bound_round(prev_best, prev_found, x, y, z, px, py, pz), best, bi);
+    nn_query_group<false>(b, x, y, z, alive, nn_warm_bound_round(prev_best, prev_found, x, y, z, px, py, pz), best, bi);
     prev_found = alive && bi != 0x7FFFFFFF;
     prev_best = best;
     px = x; py = y; pz = z;

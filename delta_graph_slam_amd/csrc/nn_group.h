@@ -145,7 +145,9 @@ __device__ __forceinline__ float nn_warm_bound_round(float prev_best, bool prev_
 // visiting a leaf like a node so that every step is uniform -- the re-visits of the last level cost more than the divergence.)
 // All 8 lanes return the same (best, best_idx); best_idx == 0x7FFFFFFF: nothing within `bound` (then best is meaningless).
 // Lanes of a wave whose group is idle must still call this with `alive` = false (they follow the control flow only).
-template <class PT>
+// WANT_INDEX = false (fitness: only the distance matters): best_idx is just 0 / 0x7FFFFFFF for found / not found, and ties need no
+// second reduction.
+template <class PT, bool WANT_INDEX>
 __device__ __forceinline__ void nn_query_group_t(const BvhView& b, float x, float y, float z, bool alive, float bound, float& best, int& best_idx) {
   const int lane = threadIdx.x & 63;
   const unsigned sub = lane & 7, gshift = lane & ~7, bit = 1u << sub;
@@ -192,11 +194,16 @@ __device__ __forceinline__ void nn_query_group_t(const BvhView& b, float x, floa
           // non-negative floats order like their bit patterns; NaN (padding / non-finite points) sorts above +inf
           const unsigned dbits = __float_as_uint(dp);
           const unsigned dmin = group8_min_u32(dbits);
-          const unsigned imin = group8_min_u32((dbits == dmin) ? __float_as_uint(p.w) : 0xFFFFFFFFu);
           const unsigned bbits = __float_as_uint(best);
-          if (dmin < bbits || (dmin == bbits && (int)imin < best_idx)) {
+          if (WANT_INDEX) {
+            const unsigned imin = group8_min_u32((dbits == dmin) ? __float_as_uint(p.w) : 0xFFFFFFFFu);
+            if (dmin < bbits || (dmin == bbits && (int)imin < best_idx)) {
+              best = __uint_as_float(dmin);
+              best_idx = (int)imin;
+            }
+          } else if (dmin <= bbits && dmin < 0x7F800000u) {  // a finite distance within the bound: found
             best = __uint_as_float(dmin);
-            best_idx = (int)imin;
+            best_idx = 0;
           }
           mask &= (unsigned)(__ballot(d <= best) >> gshift) & 0xFFu;
         }
@@ -220,11 +227,12 @@ __device__ __forceinline__ void nn_query_group_t(const BvhView& b, float x, floa
 #endif
 }
 
+template <bool WANT_INDEX = true>
 __device__ __forceinline__ void nn_query_group(const BvhView& b, float x, float y, float z, bool alive, float bound, float& best, int& best_idx) {
   if (b.depth <= 5)
-    nn_query_group_t<unsigned>(b, x, y, z, alive, bound, best, best_idx);
+    nn_query_group_t<unsigned, WANT_INDEX>(b, x, y, z, alive, bound, best, best_idx);
   else
-    nn_query_group_t<unsigned long long>(b, x, y, z, alive, bound, best, best_idx);
+    nn_query_group_t<unsigned long long, WANT_INDEX>(b, x, y, z, alive, bound, best, best_idx);
 }
 
 // ---- exact k-NN for the 8-lane group (k <= 32): the k best (distance, index) pairs live in registers, 4 slots per lane, as an
