@@ -121,8 +121,9 @@ __device__ __forceinline__ bool nn_pop(const PT pend, int& node, int& sh) {
 // of the bounded search is the exact NN (and the same index on ties) as the unbounded one.
 __device__ __forceinline__ float nn_warm_bound(float prev_best, bool prev_found, float x, float y, float z, float px, float py, float pz) {
   if (!prev_found) return INFINITY;
-  const float step = sqrtf(sqdist_rn(x, y, z, px, py, pz));
-  const float r = (sqrtf(prev_best) + step) * 1.0001f + 1e-30f;
+  // hardware square roots (1 ulp): the bound is inflated by 1e-4 anyway, and a correctly rounded sqrtf costs ~20 instructions
+  const float step = __builtin_amdgcn_sqrtf(sqdist_rn(x, y, z, px, py, pz));
+  const float r = (__builtin_amdgcn_sqrtf(prev_best) + step) * 1.0001f + 1e-30f;
   const float b2 = r * r;
   return (b2 == b2) ? b2 : INFINITY;
 }
