@@ -322,6 +322,7 @@ __device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, 
     J[6][0] = (float)(cx * cz - sx * sy * sz);  J[6][1] = (float)(-cx * sz - sx * sy * cz); J[6][2] = 0.f;
     J[7][0] = (float)(sx * cz + cx * sy * sz);  J[7][1] = (float)(cx * sy * cz - sx * sz);  J[7][2] = 0.f;
     float (*H)[3] = st->hang;
+    if (need_hessian) {  // a score + gradient evaluation (More-Thuente trial) never reads the second-derivative tables
     H[0][0] = (float)(-cx * sz - sx * sy * cz); H[0][1] = (float)(-cx * cz + sx * sy * sz); H[0][2] = (float)(sx * cy);    // a2
     H[1][0] = (float)(-sx * sz + cx * sy * cz); H[1][1] = (float)(-cx * sy * sz - sx * cz); H[1][2] = (float)(-cx * cy);   // a3
     H[2][0] = (float)(cx * cy * cz);            H[2][1] = (float)(-cx * cy * sz);           H[2][2] = (float)(cx * sy);    // b2
@@ -338,6 +339,7 @@ __device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, 
     H[12][0] = (float)(-cy * cz);               H[12][1] = (float)(cy * sz);                H[12][2] = 0.f;                // f1
     H[13][0] = (float)(-cx * sz - sx * sy * cz); H[13][1] = (float)(-cx * cz + sx * sy * sz); H[13][2] = 0.f;              // f2
     H[14][0] = (float)(-sx * sz + cx * sy * cz); H[14][1] = (float)(-cx * sy * sz - sx * cz); H[14][2] = 0.f;              // f3
+    }
     st->need_hessian = need_hessian;
   }
 #pragma unroll
