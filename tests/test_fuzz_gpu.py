@@ -3,6 +3,8 @@ duplicate and non-finite points, thin and tiny clouds, random resolutions / sear
 NDT derivatives vs the oracle (the per-evaluation tier of DESIGN.md "NDT sensitivity"), GICP / VGICP linearisation vs the
 oracle, and exactness of the fitness score against a kd-tree.  Final poses are compared where the optimiser is well
 conditioned (double-precision GICP / VGICP)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,8 @@ from delta_graph_slam_amd import synth
 from tests.helpers import f32_sqdist, f32_transform, pose_error
 
 pytestmark = pytest.mark.gpu
+
+SCALE = int(os.environ.get("DGS_FUZZ_SCALE", "1"))   # DGS_FUZZ_SCALE=8 for a longer soak (more scenes, same seeds first)
 
 
 def _scene(rng, n):
@@ -51,7 +55,7 @@ def test_ndt_derivatives_sweep(oracle_lib):
     from delta_graph_slam_amd import _lib as L
     from delta_graph_slam_amd.registration import Registration
     worst = 0.0
-    for c, rng, tgt, src, T in _cases(48, 11):
+    for c, rng, tgt, src, T in _cases(48 * SCALE, 11):
         res = float(rng.choice([0.5, 0.8, 1.0, 1.7, 2.0]))
         search = str(rng.choice(["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"]))
         tgt = tgt.copy()
@@ -84,7 +88,7 @@ def test_ndt_derivatives_sweep(oracle_lib):
 def test_gicp_family_sweep(oracle_lib, method):
     from delta_graph_slam_amd import _lib as L
     from delta_graph_slam_amd.registration import Registration
-    for c, rng, tgt, src, T in _cases(24, 23):
+    for c, rng, tgt, src, T in _cases(24 * SCALE, 23):
         k = int(rng.choice([5, 10, 20]))
         if method == "FAST_GICP":
             dmax = float(rng.choice([0.5, 1.0, 2.5]))
@@ -119,7 +123,7 @@ def test_fitness_sweep_is_exact():
     from scipy.spatial import cKDTree
     from delta_graph_slam_amd.registration import Registration
     r = Registration("NDT_OMP")
-    for c, rng, tgt, src, T in _cases(16, 37):
+    for c, rng, tgt, src, T in _cases(16 * SCALE, 37):
         tgt = tgt.copy()
         tgt[::97, 0] = np.nan                           # holes in the target
         clean = tgt[np.isfinite(tgt).all(1)]
