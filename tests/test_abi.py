@@ -36,9 +36,10 @@ def test_struct_layouts_match_the_header():
 #include <stddef.h>
 #include "dgs_reg.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(dgs_params), sizeof(dgs_result), offsetof(dgs_params, transformation_epsilon),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(dgs_params), sizeof(dgs_result), offsetof(dgs_params, transformation_epsilon),
          offsetof(dgs_params, ndt_resolution), offsetof(dgs_params, gicp_max_correspondence_distance),
-         offsetof(dgs_params, gicp_lm_max_iterations), offsetof(dgs_result, score));
+         offsetof(dgs_params, gicp_lm_max_iterations), offsetof(dgs_result, score), offsetof(dgs_params, vgicp_search_method),
+         offsetof(dgs_params, vgicp_resolution));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -49,14 +50,15 @@ int main(void) {
         vals = [int(x) for x in subprocess.check_output([exe]).split()]
     P, R = L.Params, L.Result
     assert vals == [C.sizeof(P), C.sizeof(R), P.transformation_epsilon.offset, P.ndt_resolution.offset,
-                    P.gicp_max_correspondence_distance.offset, P.gicp_lm_max_iterations.offset, R.score.offset]
+                    P.gicp_max_correspondence_distance.offset, P.gicp_lm_max_iterations.offset, R.score.offset,
+                    P.vgicp_search_method.offset, P.vgicp_resolution.offset]
 
 
 def test_defaults_are_the_reference_factory_defaults():
     """registrations.cpp:26-36,93-119: eps 0.01, 64 iterations, NDT resolution 0.5, DIRECT7, GICP dmax 2.5, k 20."""
     from delta_graph_slam_amd import _lib as L
     lib = L.load()
-    for method in (L.METHOD_NDT, L.METHOD_GICP):
+    for method in (L.METHOD_NDT, L.METHOD_GICP, L.METHOD_VGICP):
         p = L.Params()
         assert lib.dgs_params_init(C.byref(p), method) == 0
         assert p.struct_size == C.sizeof(L.Params) and p.method == method
@@ -65,6 +67,7 @@ def test_defaults_are_the_reference_factory_defaults():
         assert p.ndt_step_size == 0.1 and p.ndt_outlier_ratio == 0.55 and p.ndt_min_points_per_voxel == 6
         assert p.gicp_max_correspondence_distance == 2.5 and p.gicp_correspondence_randomness == 20
         assert p.gicp_regularization == L.GICP_REG["PLANE"] and p.gicp_rotation_epsilon == 2e-3
+        assert p.vgicp_resolution == 1.0 and p.vgicp_search_method == L.VGICP_SEARCH["DIRECT1"]      # registrations.cpp:52, FastVGICP ctor
     assert lib.dgs_params_init(C.byref(L.Params()), 7) == 1      # unknown method: DGS_ERR_INVALID_ARGUMENT
     assert lib.dgs_params_init(None, 0) == 1
 
