@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgs_reg.so")
+LIB_PATH = os.environ.get("DGS_REG_LIB") or os.path.join(_HERE, "libdgs_reg.so")   # DGS_REG_LIB: an alternative build (A/B runs)
 
 DGS_OK = 0
 STATUS = {0: "DGS_OK", 1: "DGS_ERR_INVALID_ARGUMENT", 2: "DGS_ERR_HIP", 3: "DGS_ERR_NO_TARGET", 4: "DGS_ERR_NO_SOURCE",
