@@ -14,6 +14,7 @@ STATUS = {0: "DGS_OK", 1: "DGS_ERR_INVALID_ARGUMENT", 2: "DGS_ERR_HIP", 3: "DGS_
 METHOD_NDT, METHOD_GICP, METHOD_VGICP = 0, 1, 2
 VGICP_SEARCH = {"DIRECT1": 0, "DIRECT7": 1, "DIRECT27": 2}
 NDT_SEARCH = {"KDTREE": 0, "DIRECT26": 1, "DIRECT7": 2, "DIRECT1": 3}
+NDT_ORDER = {"FAST": 0, "UPSTREAM": 1, "UPSTREAM_SEQUENTIAL": 2}
 GICP_REG = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}
 K_NDT_DERIVATIVES, K_NDT_SOLVE, K_NDT_VOXEL_BUILD, K_NN_SEARCH, K_GICP_LINEARIZE, K_GICP_COVARIANCE, K_TRANSFORM = range(7)
 
@@ -31,6 +32,7 @@ class Params(C.Structure):
         ("ndt_resolution", C.c_double), ("ndt_step_size", C.c_double), ("ndt_outlier_ratio", C.c_double),
         ("ndt_min_covar_eigvalue_mult", C.c_double), ("ndt_min_points_per_voxel", C.c_int32),
         ("ndt_line_search", C.c_int32), ("ndt_mt_max_step_iterations", C.c_int32), ("ndt_fix_hessian_d1", C.c_int32),
+        ("ndt_strict_order", C.c_int32),
         ("gicp_max_correspondence_distance", C.c_double), ("gicp_rotation_epsilon", C.c_double),
         ("gicp_lm_init_lambda_factor", C.c_double), ("gicp_correspondence_randomness", C.c_int32),
         ("gicp_regularization", C.c_int32), ("gicp_optimizer", C.c_int32), ("gicp_lm_max_iterations", C.c_int32),

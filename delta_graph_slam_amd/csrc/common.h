@@ -15,6 +15,8 @@ constexpr int kBlock = 256;        // 4 waves per workgroup: one wave per SIMD
 constexpr int kAccum = 28;         // score + 6 gradient + 21 upper-triangle Hessian terms
 constexpr int kAccumPad = 32;      // partial-sum row stride (doubles)
 constexpr int kMaxPartialBlocks = 1024;  // per pair
+constexpr int kStrictAccum = 43;   // ndt_strict_order: score + 6 gradient + the full 6x6 Hessian (upstream's is not exactly symmetric)
+constexpr int kStrictPad = 48;
 constexpr int kTrajCap = 72;
 
 // ---- NDT voxel-Gaussian target model in HBM ------------------------------------------------------------
@@ -141,6 +143,7 @@ struct NdtConsts {
   double step_size, trans_eps;
   int max_iterations, line_search, mt_max_step_iterations, fix_hessian_d1;
   int search_method;
+  int strict_order;  // dgs_ndt_strict_order
 };
 
 struct NdtInit {  // host -> device per pair, per align
@@ -232,6 +235,35 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
 // pcl::transformPointCloud row in float: ((m0 x + m1 y) + m2 z) + m3, every step rounded
 __device__ __forceinline__ float affine_row_rn(float m0, float m1, float m2, float m3, float x, float y, float z) {
   return add_rn(add_rn(add_rn(mul_rn(m0, x), mul_rn(m1, y)), mul_rn(m2, z)), m3);
+}
+// exp(float) as a fixed sequence of IEEE double operations rounded once to float (no contraction): platform independent, within
+// ~1e-16 of exp before the rounding.  ndt_strict_order evaluations use it so that a CPU run of the same sequence (the checker
+// carries its own statement of it) can be compared bit for bit; the default path uses the hardware exponential.
+__device__ __forceinline__ float det_expf(float xf) {
+#pragma clang fp contract(off)
+  const double x = (double)xf;
+  if (x != x) return xf;
+  if (x < -104.0) return 0.0f;  // below half the smallest subnormal float
+  if (x > 89.0) return __builtin_inff();
+  const double kd = floor(x * 1.4426950408889634 + 0.5);  // round(x / ln 2)
+  const double r = (x - kd * 0x1.62e42fefa38p-1) - kd * 0x1.ef35793c7673p-45;  // ln 2 split hi / lo; |r| <= 0.3466
+  double p = 1.0 / 6227020800.0;  // Taylor to r^13 / 13!
+  p = p * r + 1.0 / 479001600.0;
+  p = p * r + 1.0 / 39916800.0;
+  p = p * r + 1.0 / 3628800.0;
+  p = p * r + 1.0 / 362880.0;
+  p = p * r + 1.0 / 40320.0;
+  p = p * r + 1.0 / 5040.0;
+  p = p * r + 1.0 / 720.0;
+  p = p * r + 1.0 / 120.0;
+  p = p * r + 1.0 / 24.0;
+  p = p * r + 1.0 / 6.0;
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  const long long k = (long long)kd;
+  const double s = __longlong_as_double((k + 1023) << 52);  // 2^k, k in [-151, 129]: a normal double
+  return (float)(p * s);
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

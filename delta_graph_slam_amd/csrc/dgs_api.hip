@@ -166,6 +166,7 @@ int dgs_params_init(dgs_params* p, int32_t method) {
   p->ndt_line_search = DGS_NDT_LS_MORE_THUENTE;
   p->ndt_mt_max_step_iterations = 10;
   p->ndt_fix_hessian_d1 = 0;
+  p->ndt_strict_order = DGS_NDT_ORDER_FAST;
   p->gicp_max_correspondence_distance = 2.5;
   p->gicp_rotation_epsilon = 2e-3;
   p->gicp_lm_init_lambda_factor = 1e-9;
@@ -185,6 +186,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (params->method == DGS_METHOD_VGICP && (!(params->vgicp_resolution > 0) || params->vgicp_search_method < 0 || params->vgicp_search_method > DGS_VGICP_DIRECT27))
     return DGS_ERR_INVALID_ARGUMENT;
   if (!(params->ndt_resolution > 0) || params->maximum_iterations < 0 || params->gicp_correspondence_randomness < 1) return DGS_ERR_INVALID_ARGUMENT;
+  if (params->ndt_strict_order < DGS_NDT_ORDER_FAST || params->ndt_strict_order > DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) return DGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   dgs_handle* h = new (std::nothrow) dgs_handle();
   if (!h) return DGS_ERR_HIP;
@@ -229,7 +231,7 @@ void dgs_destroy(dgs_handle* h) {
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
   h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
-  h->nn_partials.release(); h->scratch_cloud.release();
+  h->nn_partials.release(); h->scratch_cloud.release(); h->strict_rows.release(); h->strict_totals.release();
   h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_out.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
   h->aux_bvh.keys.release(); h->aux_bvh.keys_alt.release(); h->aux_bvh.vals.release(); h->aux_bvh.vals_alt.release();
   h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();

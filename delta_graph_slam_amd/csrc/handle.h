@@ -103,6 +103,8 @@ struct dgs_handle {
   dgs::DevBuf<double> partials;       // [pair][block][kAccumPad]
   dgs::DevBuf<int> done_counter;      // [0] = finished pairs
   dgs::DevBuf<int> pair_blocks;       // slices the last derivative launch gave each pair
+  dgs::DevBuf<double> strict_rows;    // ndt_strict_order 2: per-point totals, [pair][43][max_n] (column-major per pair)
+  dgs::DevBuf<double> strict_totals;  // ndt_strict_order 1/2: [pair][kStrictPad] sums of one evaluation
   dgs::DevBuf<const float4*> src_ptrs;
   dgs::DevBuf<int> src_sizes;
   dgs::NdtConsts consts{};

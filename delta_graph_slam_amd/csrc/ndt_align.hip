@@ -258,6 +258,211 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
   }
 }
 
+// Everything below this line -- the validation-mode evaluation, the optimiser (Newton step, More-Thuente state machine,
+// transform / angle tables of the next evaluation) and the host code -- is compiled with floating-point contraction OFF: each
+// operation is rounded on its own, as in a CPU build of upstream without FMA, so the optimiser's double arithmetic follows the
+// CPU checker operation for operation.  Only the default derivative kernel above lets the compiler fuse multiply-adds.
+#pragma clang fp contract(off)
+
+// ================================================================================================ validation modes
+// dgs_params.ndt_strict_order >= 1: computeDerivatives / updateDerivatives in upstream's own operation order (SURVEY.md App. A
+// "Per point"; the CPU checker states the same sequence).  Per point: float point gradient (3x6) and second-derivative
+// vectors, then per neighbour voxel q = float(double(x') - mean), C = float(icov) (all 9 entries: after the eigenvalue clamp
+// the covariance is rebuilt as V diag V^-1 and is not exactly symmetric), q^T C, exp, the float 3x6 product C * J, the float
+// gradient / Hessian increments, each converted and added to the point's DOUBLE totals.  One point -> 43 doubles.
+template <int SEARCH>
+__device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T, const NdtPair& st, const VoxelGrid& g, const double* __restrict__ vtab,
+                                                 const double gauss_d1, const float gd2, const int leaf_pow2, const bool need_h, double* out) {
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) out[k] = 0.0;
+  float xt[3];
+  xt[0] = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
+  xt[1] = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
+  xt[2] = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
+  const int c0 = (int)floorf(leaf_pow2 ? xt[0] * g.inv_leaf : xt[0] / g.leaf);
+  const int c1 = (int)floorf(leaf_pow2 ? xt[1] * g.inv_leaf : xt[1] / g.leaf);
+  const int c2 = (int)floorf(leaf_pow2 ? xt[2] * g.inv_leaf : xt[2] / g.leaf);
+  constexpr int NB = Offsets<SEARCH>::N;
+  const float r2 = g.leaf * g.leaf;
+  // computePointDerivatives
+  const float xp[3] = {x.x, x.y, x.z};
+  float pg[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+  float xj[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) xj[i] = st.jang[i][0] * xp[0] + st.jang[i][1] * xp[1] + st.jang[i][2] * xp[2];
+  pg[1][3] = xj[0]; pg[2][3] = xj[1];
+  pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4];
+  pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
+  float ph[6][6][3];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) ph[i][j][0] = ph[i][j][1] = ph[i][j][2] = 0.f;
+  if (need_h) {
+    float xh[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) xh[i] = st.hang[i][0] * xp[0] + st.hang[i][1] * xp[1] + st.hang[i][2] * xp[2];
+    const float a[3] = {0, xh[0], xh[1]}, b[3] = {0, xh[2], xh[3]}, c[3] = {0, xh[4], xh[5]};
+    const float d[3] = {xh[6], xh[7], xh[8]}, e[3] = {xh[9], xh[10], xh[11]}, f[3] = {xh[12], xh[13], xh[14]};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      ph[3][3][r] = a[r]; ph[3][4][r] = b[r]; ph[3][5][r] = c[r];
+      ph[4][3][r] = b[r]; ph[4][4][r] = d[r]; ph[4][5][r] = e[r];
+      ph[5][3][r] = c[r]; ph[5][4][r] = e[r]; ph[5][5][r] = f[r];
+    }
+  }
+  double score_pt = 0.0, g_pt[6] = {0, 0, 0, 0, 0, 0}, h_pt[36];
+#pragma unroll
+  for (int k = 0; k < 36; k++) h_pt[k] = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < NB; k++) {
+    int dx, dy, dz;
+    neighbour_offset<SEARCH>(k, dx, dy, dz);
+    const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
+    const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
+    const int vid = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+    if (vid < 0) continue;
+    if (SEARCH == DGS_NDT_KDTREE) {
+      const float4 ce = g.centroid[vid];
+      const float ex = ce.x - xt[0], ey = ce.y - xt[1], ez = ce.z - xt[2];
+      if (!(ex * ex + ey * ey + ez * ez < r2)) continue;
+    }
+    const double* __restrict__ rec = vtab + (size_t)vid * 12;  // mean[3], icov[9] (row-major), double
+    float q[3], C[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) q[r] = (float)((double)xt[r] - rec[r]);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) C[r][c] = (float)rec[3 + r * 3 + c];
+    float qC[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) qC[c] = q[0] * C[0][c] + q[1] * C[1][c] + q[2] * C[2][c];
+    float e_x_cov_x = det_expf(-gd2 * (q[0] * qC[0] + q[1] * qC[1] + q[2] * qC[2]) * 0.5f);
+    const float score_inc = (float)(-gauss_d1 * (double)e_x_cov_x);
+    e_x_cov_x = gd2 * e_x_cov_x;
+    if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
+    e_x_cov_x = (float)((double)e_x_cov_x * gauss_d1);
+    float cPG[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) cPG[r][c] = C[r][0] * pg[0][c] + C[r][1] * pg[1][c] + C[r][2] * pg[2][c];
+    float g6[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) g6[c] = q[0] * cPG[0][c] + q[1] * cPG[1][c] + q[2] * cPG[2][c];
+#pragma unroll
+    for (int c = 0; c < 6; c++) g_pt[c] += (double)(e_x_cov_x * g6[c]);
+    if (need_h) {
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const float xCH = qC[0] * ph[i][j][0] + qC[1] * ph[i][j][1] + qC[2] * ph[i][j][2];
+          const float pcp = pg[0][j] * cPG[0][i] + pg[1][j] * cPG[1][i] + pg[2][j] * cPG[2][i];
+          h_pt[i * 6 + j] += (double)(e_x_cov_x * (-gd2 * g6[i] * g6[j] + xCH + pcp));
+        }
+    }
+    score_pt += (double)score_inc;
+  }
+  out[0] = score_pt;
+#pragma unroll
+  for (int k = 0; k < 6; k++) out[1 + k] = g_pt[k];
+#pragma unroll
+  for (int k = 0; k < 36; k++) out[7 + k] = h_pt[k];
+}
+
+// ROWS = false (ndt_strict_order 1): per-thread double totals over a strided set of points, block sums in a fixed order, one
+// 48-double row per workgroup.  ROWS = true (ndt_strict_order 2): the 43 per-point totals go to HBM, column-major per pair
+// ([43][max_n]), for the sequential index-order sum of ndt_strict_seqsum_kernel.
+template <int SEARCH, bool ROWS>
+__global__ __launch_bounds__(kBlock) void ndt_derivatives_strict_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
+                                                                        const NdtPair* __restrict__ pairs, const VoxelGrid g,
+                                                                        const double* __restrict__ vtab, const double gauss_d1, const float gd2,
+                                                                        const int leaf_pow2, double* __restrict__ partials, double* __restrict__ rows,
+                                                                        const int max_n, const int n_pairs, const int cap_blocks,
+                                                                        int* __restrict__ pair_blocks) {
+  int pair, slice, blocks_per_pair;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, blocks_per_pair)) return;
+  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
+  const NdtPair& st = pairs[pair];
+  const float4* __restrict__ src = src_ptrs[pair];
+  const int n = src_sizes[pair];
+  const bool need_h = st.need_hessian != 0;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st.T[k];
+  double acc[kStrictAccum];
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) acc[k] = 0.0;
+  const int ncol = need_h ? kStrictAccum : 7;
+  for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
+    double o[kStrictAccum];
+    ndt_point_strict<SEARCH>(src[i], T, st, g, vtab, gauss_d1, gd2, leaf_pow2, need_h, o);
+    if (ROWS) {
+      double* __restrict__ col = rows + (size_t)pair * kStrictAccum * max_n + i;
+      for (int k = 0; k < ncol; k++) col[(size_t)k * max_n] = o[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < kStrictAccum; k++) acc[k] += o[k];
+    }
+  }
+  if (ROWS) return;
+  __shared__ double sm[kBlock / kWave][kStrictPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) sm[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kStrictPad) {
+    double v = 0.0;
+    if (threadIdx.x < kStrictAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    partials[((size_t)pair * cap_blocks + slice) * kStrictPad + threadIdx.x] = v;
+  }
+}
+
+// ndt_strict_order 1: block rows -> totals, one wave per pair, rows added in slice order
+__global__ __launch_bounds__(kWave) void ndt_strict_reduce_kernel(const NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
+                                                                  const int* __restrict__ pair_blocks, double* __restrict__ totals) {
+  const int pair = blockIdx.x;
+  if (!pairs[pair].active) return;
+  const int nb = pair_blocks[pair];
+  if (threadIdx.x >= kStrictPad) return;
+  double v = 0.0;
+  const double* base = partials + (size_t)pair * cap_blocks * kStrictPad;
+  for (int b = 0; b < nb; b++) v += base[(size_t)b * kStrictPad + threadIdx.x];
+  totals[(size_t)pair * kStrictPad + threadIdx.x] = v;
+}
+
+// ndt_strict_order 2: upstream's final loop -- score / gradient / Hessian entries summed over the points in index order, one
+// lane per entry (a dependent chain of n double additions: this mode exists to prove bit-parity, not to be fast)
+__global__ __launch_bounds__(kWave) void ndt_strict_seqsum_kernel(const NdtPair* __restrict__ pairs, const int* __restrict__ src_sizes,
+                                                                  const double* __restrict__ rows, const int max_n, double* __restrict__ totals) {
+  const int pair = blockIdx.x;
+  const NdtPair& st = pairs[pair];
+  if (!st.active) return;
+  const int ncol = st.need_hessian ? kStrictAccum : 7;
+  const int c = threadIdx.x;
+  if (c >= kStrictPad) return;
+  double v = 0.0;
+  if (c < ncol) {
+    const int n = src_sizes[pair];
+    const double* __restrict__ col = rows + ((size_t)pair * kStrictAccum + c) * max_n;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = col[i + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v += t[u];
+    }
+    for (; i < n; i++) v += col[i];
+  }
+  totals[(size_t)pair * kStrictPad + c] = v;
+}
+
 // ================================================================================================ solver
 // float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap),
 // written to the pair's HBM record by lane 0 (`writer`); every lane computes the same values.
@@ -404,8 +609,12 @@ __device__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, b
   double neg_g[6], delta[6], rc;
 #pragma unroll
   for (int k = 0; k < 6; k++) neg_g[k] = -s.grad[k];
-  gj_solve6_wave(s.hess, neg_g, delta, &rc);
-  if (!(rc > 1e-13)) svd_solve6_dev(s.hess, neg_g, delta);
+  if (c.strict_order) {  // JacobiSVD(H).solve(-g), the sequence of operations of the CPU checker
+    svd_solve6_dev(s.hess, neg_g, delta, 1e-17, 60);
+  } else {
+    gj_solve6_wave(s.hess, neg_g, delta, &rc);
+    if (!(rc > 1e-13)) svd_solve6_dev(s.hess, neg_g, delta);
+  }
   double norm = sqrt(dot6(delta, delta));
   if (norm == 0 || norm != norm) {
     s.converged = (norm == norm) ? 1 : 0;
@@ -547,7 +756,8 @@ __device__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool 
 }
 
 __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
-                                                           const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter) {
+                                                           const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter,
+                                                           const double* __restrict__ strict_totals) {
   const int pair = blockIdx.x;
   NdtPair* st = pairs + pair;
   // Everything this kernel reads was written by the previous launch, i.e. comes from HBM: issue the independent loads (active
@@ -561,23 +771,29 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
     need_h = st->need_hessian;
   }
   if (!active) return;
-  // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
-  __shared__ double sm[kBlock / kAccumPad][kAccumPad];
-  const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
-  constexpr int G = kBlock / kAccumPad;
-  double v = 0.0;
-  const double* base = partials + (size_t)pair * cap_blocks * kAccumPad;
-  for (int b = grp; b < blocks_per_pair; b += G) v += base[(size_t)b * kAccumPad + col];
-  sm[grp][col] = v;
-  __syncthreads();
-  __shared__ double tot[kAccumPad];
-  if (threadIdx.x < kAccumPad) {
-    double t = 0.0;
+  __shared__ double tot[kStrictPad];
+  if (strict_totals) {
+    // validation modes: the sums of this evaluation were formed by ndt_strict_reduce / ndt_strict_seqsum
+    if (threadIdx.x < kStrictPad) tot[threadIdx.x] = strict_totals[(size_t)pair * kStrictPad + threadIdx.x];
+    __syncthreads();
+  } else {
+    // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
+    __shared__ double sm[kBlock / kAccumPad][kAccumPad];
+    const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
+    constexpr int G = kBlock / kAccumPad;
+    double v = 0.0;
+    const double* base = partials + (size_t)pair * cap_blocks * kAccumPad;
+    for (int b = grp; b < blocks_per_pair; b += G) v += base[(size_t)b * kAccumPad + col];
+    sm[grp][col] = v;
+    __syncthreads();
+    if (threadIdx.x < kAccumPad) {
+      double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
-    tot[threadIdx.x] = t;
+      for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
+      tot[threadIdx.x] = t;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x >= kWave) return;
   // ---- one wave advances the optimiser: state in registers, every lane computes the same values, lane 0 writes
   const bool writer = threadIdx.x == 0;
@@ -585,15 +801,20 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
 #pragma unroll
   for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];
   if (need_h) {
-    int q = 7;
+    if (strict_totals) {
 #pragma unroll
-    for (int i = 0; i < 6; i++)
+      for (int k = 0; k < 36; k++) s.hess[k] = tot[7 + k];  // upstream's full 6x6 (not exactly symmetric in float)
+    } else {
+      int q = 7;
 #pragma unroll
-      for (int j = i; j < 6; j++) {
-        s.hess[i * 6 + j] = tot[q];
-        s.hess[j * 6 + i] = tot[q];
-        q++;
-      }
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) {
+          s.hess[i * 6 + j] = tot[q];
+          s.hess[j * 6 + i] = tot[q];
+          q++;
+        }
+    }
   }
   ndt_advance(st, s, c, writer);
   if (writer) {
@@ -693,13 +914,27 @@ static void fill_consts(dgs_handle* h) {
   c.mt_max_step_iterations = p.ndt_mt_max_step_iterations;
   c.fix_hessian_d1 = p.ndt_fix_hessian_d1;
   c.search_method = p.ndt_search_method;
+  c.strict_order = p.ndt_strict_order;
 }
 
 struct NdtLaunch {
   int n_pairs;
   int cap_blocks;    // most slices one pair can get (= rows reserved per pair in `partials`)
   int total_blocks;  // workgroups per derivative launch
+  int max_n;         // largest source of the batch (row length of the ndt_strict_order 2 per-point table)
 };
+
+template <int SEARCH>
+static void launch_strict(dgs_handle* h, const NdtLaunch& L, const dim3 grid, const int leaf_pow2) {
+  const double gd1 = h->consts.gauss_d1;
+  const float gd2 = (float)h->consts.gauss_d2;
+  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL)
+    hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
+                       h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
+  else
+    hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, false>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
+                       h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
+}
 
 static void launch_derivatives(dgs_handle* h, const NdtLaunch& L) {
   const dim3 grid(L.total_blocks), block(kBlock);
@@ -707,6 +942,22 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L) {
   int fe = 0;
   const int leaf_pow2 = (std::frexp(h->grid.leaf, &fe) == 0.5f) ? 1 : 0;
   int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES);
+  if (h->consts.strict_order != DGS_NDT_ORDER_FAST) {
+    switch (h->consts.search_method) {
+      case DGS_NDT_DIRECT1: launch_strict<DGS_NDT_DIRECT1>(h, L, grid, leaf_pow2); break;
+      case DGS_NDT_DIRECT26: launch_strict<DGS_NDT_DIRECT26>(h, L, grid, leaf_pow2); break;
+      case DGS_NDT_KDTREE: launch_strict<DGS_NDT_KDTREE>(h, L, grid, leaf_pow2); break;
+      default: launch_strict<DGS_NDT_DIRECT7>(h, L, grid, leaf_pow2); break;
+    }
+    if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL)
+      hipLaunchKernelGGL(ndt_strict_seqsum_kernel, dim3(L.n_pairs), dim3(kWave), 0, h->stream, h->pairs.ptr, h->src_sizes.ptr, h->strict_rows.ptr, L.max_n,
+                         h->strict_totals.ptr);
+    else
+      hipLaunchKernelGGL(ndt_strict_reduce_kernel, dim3(L.n_pairs), dim3(kWave), 0, h->stream, h->pairs.ptr, h->partials.ptr, L.cap_blocks, h->pair_blocks.ptr,
+                         h->strict_totals.ptr);
+    prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
+    return;
+  }
   switch (h->consts.search_method) {
     case DGS_NDT_DIRECT1:
       hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT1>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
@@ -731,7 +982,7 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L) {
 static void launch_solve(dgs_handle* h, const NdtLaunch& L) {
   int slot = prof_begin(h, DGS_K_NDT_SOLVE);
   hipLaunchKernelGGL(ndt_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->pairs.ptr, h->partials.ptr, L.cap_blocks, h->pair_blocks.ptr, h->consts,
-                     h->done_counter.ptr);
+                     h->done_counter.ptr, h->consts.strict_order != DGS_NDT_ORDER_FAST ? h->strict_totals.ptr : nullptr);
   prof_end(h, DGS_K_NDT_SOLVE, slot);
 }
 
@@ -740,6 +991,7 @@ static NdtLaunch choose_launch(int n_pairs, int max_n) {
   L.n_pairs = n_pairs;
   L.cap_blocks = std::max(1, std::min((max_n + kBlock - 1) / kBlock, 128));                 // at most 128 slices (partial rows) per pair
   L.total_blocks = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_blocks, 1024));  // ~4 workgroups per CU
+  L.max_n = std::max(max_n, 1);
   return L;
 }
 
@@ -756,7 +1008,9 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
   DGS_HIP_TRY(h, h->inits.reserve(n_pairs));
   DGS_HIP_TRY(h, h->src_ptrs.reserve(n_pairs));
   DGS_HIP_TRY(h, h->src_sizes.reserve(n_pairs));
-  DGS_HIP_TRY(h, h->partials.reserve((size_t)n_pairs * L.cap_blocks * kAccumPad));
+  DGS_HIP_TRY(h, h->partials.reserve((size_t)n_pairs * L.cap_blocks * (h->consts.strict_order ? kStrictPad : kAccumPad)));
+  if (h->consts.strict_order) DGS_HIP_TRY(h, h->strict_totals.reserve((size_t)n_pairs * kStrictPad));
+  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) DGS_HIP_TRY(h, h->strict_rows.reserve((size_t)n_pairs * kStrictAccum * L.max_n));
   DGS_HIP_TRY(h, h->pair_blocks.reserve(n_pairs));
   DGS_HIP_TRY(h, h->done_counter.reserve(16));
   const size_t off_init = 256;

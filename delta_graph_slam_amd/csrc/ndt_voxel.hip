@@ -122,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __
                                                                 int* __restrict__ cell2vox, VoxelRec* __restrict__ vox,
                                                                 float4* __restrict__ centroid, double* __restrict__ dbg,
                                                                 int* __restrict__ vcount, int* __restrict__ vvalid) {
+#pragma clang fp contract(off)  // the table is compared bit for bit with the CPU checker: every operation individually rounded
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int num_runs = scalars[0];
   if (r >= num_runs) return;

@@ -5,6 +5,7 @@
 namespace dgs {
 
 __device__ inline bool inv3_d(const double* A, double* Ai) {
+#pragma clang fp contract(off)
   const double c00 = A[4] * A[8] - A[5] * A[7];
   const double c01 = A[5] * A[6] - A[3] * A[8];
   const double c02 = A[3] * A[7] - A[4] * A[6];
@@ -22,56 +23,59 @@ __device__ inline bool inv3_d(const double* A, double* Ai) {
   return det != 0.0;
 }
 
-// symmetric 3x3 eigen-decomposition (cyclic Jacobi, lower triangle is authoritative), ascending eigenvalues
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi with full two-sided rotations, lower triangle authoritative), ascending
+// eigenvalues.  The sequence of IEEE operations is fixed (no contraction) and is the one the CPU checker of this repository
+// executes as well, so the voxel table can be compared with it bit for bit (dgs_params.ndt_strict_order).
 __device__ inline void sym_eig3_d(const double* Ain, double* ev, double* V) {
-  double a00 = Ain[0], a11 = Ain[4], a22 = Ain[8], a01 = Ain[3], a02 = Ain[6], a12 = Ain[7];
+#pragma clang fp contract(off)
+  double A[9];
+  A[0] = Ain[0]; A[4] = Ain[4]; A[8] = Ain[8];
+  A[3] = A[1] = Ain[3]; A[6] = A[2] = Ain[6]; A[7] = A[5] = Ain[7];
   double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  for (int sweep = 0; sweep < 32; sweep++) {
-    const double off = a01 * a01 + a02 * a02 + a12 * a12;
-    const double dia = a00 * a00 + a11 * a11 + a22 * a22;
-    if (off == 0.0 || off <= 1e-34 * dia) break;
-    // rotation (0,1)
-    if (a01 != 0.0) {
-      const double th = (a11 - a00) / (2.0 * a01);
-      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-      const double n00 = a00 - t * a01, n11 = a11 + t * a01;
-      const double n02 = c * a02 - s * a12, n12 = s * a02 + c * a12;
-      a00 = n00; a11 = n11; a01 = 0.0; a02 = n02; a12 = n12;
-      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 0], y = v[k * 3 + 1]; v[k * 3 + 0] = c * x - s * y; v[k * 3 + 1] = s * x + c * y; }
-    }
-    // rotation (0,2)
-    if (a02 != 0.0) {
-      const double th = (a22 - a00) / (2.0 * a02);
-      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-      const double n00 = a00 - t * a02, n22 = a22 + t * a02;
-      const double n01 = c * a01 - s * a12, n12 = s * a01 + c * a12;
-      a00 = n00; a22 = n22; a02 = 0.0; a01 = n01; a12 = n12;
-      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 0], y = v[k * 3 + 2]; v[k * 3 + 0] = c * x - s * y; v[k * 3 + 2] = s * x + c * y; }
-    }
-    // rotation (1,2)
-    if (a12 != 0.0) {
-      const double th = (a22 - a11) / (2.0 * a12);
-      const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-      const double n11 = a11 - t * a12, n22 = a22 + t * a12;
-      const double n01 = c * a01 - s * a02, n02 = s * a01 + c * a02;
-      a11 = n11; a22 = n22; a12 = 0.0; a01 = n01; a02 = n02;
-      for (int k = 0; k < 3; k++) { const double x = v[k * 3 + 1], y = v[k * 3 + 2]; v[k * 3 + 1] = c * x - s * y; v[k * 3 + 2] = s * x + c * y; }
-    }
+  for (int sweep = 0; sweep < 64; sweep++) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double dia = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-34 * dia || off == 0.0) break;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+      for (int q = p + 1; q < 3; q++) {
+        const double apq = A[p * 3 + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[q * 3 + q] - A[p * 3 + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {  // A <- A * J
+          const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+          A[k * 3 + p] = c * akp - s * akq;
+          A[k * 3 + q] = s * akp + c * akq;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {  // A <- J^T * A
+          const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+          A[p * 3 + k] = c * apk - s * aqk;
+          A[q * 3 + k] = s * apk + c * aqk;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const double vkp = v[k * 3 + p], vkq = v[k * 3 + q];
+          v[k * 3 + p] = c * vkp - s * vkq;
+          v[k * 3 + q] = s * vkp + c * vkq;
+        }
+      }
   }
-  double e[3] = {a00, a11, a22};
+  const double e[3] = {A[0], A[4], A[8]};
+  // stable ascending order of three values (ties keep their index order)
   int o0 = 0, o1 = 1, o2 = 2;
-  if (e[o0] > e[o1]) { int t = o0; o0 = o1; o1 = t; }
-  if (e[o1] > e[o2]) { int t = o1; o1 = o2; o2 = t; }
-  if (e[o0] > e[o1]) { int t = o0; o0 = o1; o1 = t; }
+  if (e[o1] < e[o0]) { const int t = o0; o0 = o1; o1 = t; }
+  if (e[o2] < e[o1]) { const int t = o1; o1 = o2; o2 = t; }
+  if (e[o1] < e[o0]) { const int t = o0; o0 = o1; o1 = t; }
   const int o[3] = {o0, o1, o2};
   for (int k = 0; k < 3; k++) {
     ev[k] = e[o[k]];
     for (int r = 0; r < 3; r++) V[r * 3 + k] = v[r * 3 + o[k]];
   }
 }
-
 
 }  // namespace dgs

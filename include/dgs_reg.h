@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 2
+#define DGS_ABI_VERSION 3
 
 typedef struct dgs_handle dgs_handle;
 typedef struct dgs_cloud dgs_cloud; /* a cloud resident in HBM together with its NN index / covariances (see below) */
@@ -64,6 +64,17 @@ enum dgs_ndt_search { DGS_NDT_KDTREE = 0, DGS_NDT_DIRECT26 = 1, DGS_NDT_DIRECT7 
  *   Kept because un-pinned ndt_omp forks differ here; it oscillates on planar scenes (DESIGN.md "NDT sensitivity"). */
 enum dgs_ndt_line_search { DGS_NDT_LS_FIXED_STEP = 0, DGS_NDT_LS_MORE_THUENTE = 1 };
 
+/* Order of the per-point arithmetic of NDT computeDerivatives / updateDerivatives (validation modes; DESIGN.md "Parity").
+ * FAST (default): the <= 7 voxels of a point are folded in float and projected once through the point Jacobian (1/3 of the
+ *   flops, FMA contraction allowed, hardware expf, Gauss-Jordan Newton solve): the same algebra as upstream, re-associated.
+ * UPSTREAM: every float operation of upstream's per-voxel update in upstream's order, individually rounded (no FMA), a
+ *   platform-independent exp, each voxel's increments added to the point's double totals, the full (not exactly symmetric)
+ *   6x6 Hessian, Jacobi-SVD Newton solve; the points' totals are summed in the GPU's own fixed order, so only the order of
+ *   the double summation differs from a CPU run of upstream.
+ * UPSTREAM_SEQUENTIAL: as UPSTREAM, and the per-point totals are written out and summed in point-index order like
+ *   upstream's final loop: every evaluation is bit-identical to the CPU restatement (slow: one lane per sum). */
+enum dgs_ndt_strict_order { DGS_NDT_ORDER_FAST = 0, DGS_NDT_ORDER_UPSTREAM = 1, DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL = 2 };
+
 /* fast_gicp::RegularizationMethod, same enumerator order as upstream */
 enum dgs_gicp_regularization {
   DGS_GICP_REG_NONE = 0, DGS_GICP_REG_MIN_EIG = 1, DGS_GICP_REG_NORMALIZED_MIN_EIG = 2,
@@ -91,6 +102,7 @@ typedef struct dgs_params {
   int32_t ndt_line_search;          /* dgs_ndt_line_search, default DGS_NDT_LS_MORE_THUENTE */
   int32_t ndt_mt_max_step_iterations; /* default 10 */
   int32_t ndt_fix_hessian_d1;       /* 0 = upstream h_ang_d1 table (z-term +sy); 1 = exact (-sy) */
+  int32_t ndt_strict_order;         /* dgs_ndt_strict_order, default DGS_NDT_ORDER_FAST */
 
   /* ---- GICP (fast_gicp::FastGICP) ---- */
   double gicp_max_correspondence_distance; /* setMaxCorrespondenceDistance; factory default 2.5 (registrations.cpp:33) */

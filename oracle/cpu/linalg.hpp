@@ -9,6 +9,7 @@
 //   LDLT<Matrix<double,6,6>>::solve    -> ldlt_solve6 (Bunch-Kaufman-free diagonal-pivoted LDL^T, as Eigen)
 #pragma once
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <limits>
 #include <algorithm>
@@ -86,6 +87,40 @@ inline void sym_eig3(const double* Ain, double* evals, double* V) {
     for (int r = 0; r < 3; r++) Vs[r * 3 + k] = V[r * 3 + idx[k]];
   }
   std::memcpy(V, Vs, sizeof(Vs));
+}
+
+// ---- exp(float) with a platform-independent value ------------------------------------------------------
+// Upstream calls std::exp(float), whose last bit depends on the libm at hand (glibc's expf is within 0.502 ulp and
+// even differs between its own FMA / non-FMA ifunc variants).  The restatement therefore defines it as this fixed
+// sequence of IEEE double operations (no contraction), rounded once to float: accurate to ~1e-16 before the
+// rounding, i.e. the correctly rounded expf except for ~1e-9 of the arguments, and bit-reproducible on any IEEE
+// machine -- the device library carries the same sequence, so strict-order evaluations can be compared bit for bit.
+inline float det_expf(float xf) {
+  const double x = static_cast<double>(xf);
+  if (x != x) return xf;
+  if (x < -104.0) return 0.0f;  // below half the smallest subnormal float
+  if (x > 89.0) return std::numeric_limits<float>::infinity();
+  const double kd = std::floor(x * 1.4426950408889634 + 0.5);  // round(x / ln 2)
+  const double r = (x - kd * 0x1.62e42fefa38p-1) - kd * 0x1.ef35793c7673p-45;  // ln 2 split hi / lo; |r| <= 0.3466
+  double p = 1.0 / 6227020800.0;  // Taylor to r^13 / 13!: truncation 6e-18 relative
+  p = p * r + 1.0 / 479001600.0;
+  p = p * r + 1.0 / 39916800.0;
+  p = p * r + 1.0 / 3628800.0;
+  p = p * r + 1.0 / 362880.0;
+  p = p * r + 1.0 / 40320.0;
+  p = p * r + 1.0 / 5040.0;
+  p = p * r + 1.0 / 720.0;
+  p = p * r + 1.0 / 120.0;
+  p = p * r + 1.0 / 24.0;
+  p = p * r + 1.0 / 6.0;
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  const int64_t k = static_cast<int64_t>(kd);
+  const uint64_t bits = static_cast<uint64_t>(k + 1023) << 52;  // 2^k, k in [-151, 129]: a normal double
+  double s;
+  std::memcpy(&s, &bits, sizeof(s));
+  return static_cast<float>(p * s);
 }
 
 // ---- 6x6 (row-major double[36]) -----------------------------------------------------------------

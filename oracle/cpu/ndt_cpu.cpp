@@ -287,7 +287,8 @@ double NdtCpu::derivatives_with(const float* T, const double p[6], double g[6], 
         for (int c = 0; c < 3; c++) C[r][c] = static_cast<float>(cell->icov[r * 3 + c]);
       float qC[3];
       for (int c = 0; c < 3; c++) qC[c] = q[0] * C[0][c] + q[1] * C[1][c] + q[2] * C[2][c];
-      float e_x_cov_x = std::exp(-gd2 * (q[0] * qC[0] + q[1] * qC[1] + q[2] * qC[2]) * 0.5f);
+      const float e_arg = -gd2 * (q[0] * qC[0] + q[1] * qC[1] + q[2] * qC[2]) * 0.5f;
+      float e_x_cov_x = prm.exp_libm ? std::exp(e_arg) : det_expf(e_arg);
       const float score_inc = static_cast<float>(-gauss_d1 * e_x_cov_x);
       e_x_cov_x = gd2 * e_x_cov_x;
       if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;

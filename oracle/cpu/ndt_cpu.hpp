@@ -33,6 +33,7 @@ struct NdtParams {
   int mt_max_step_iterations = 10;
   int fix_hessian_d1 = 0;                // 0 = upstream table (h_ang_d1 z-term +sy), 1 = exact second derivative (-sy)
   int num_threads = 0;                   // registrations.cpp:102,106-108 (0 = all cores)
+  int exp_libm = 0;                      // 0 = det_expf (linalg.hpp: platform-independent value of std::exp(float)), 1 = the host libm's expf
 };
 
 struct Leaf {

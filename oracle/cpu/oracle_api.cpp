@@ -27,6 +27,7 @@ void orc_ndt_default_params(orc_ndt_params* p) {
   p->mt_max_step_iterations = d.mt_max_step_iterations;
   p->num_threads = d.num_threads;
   p->fix_hessian_d1 = d.fix_hessian_d1;
+  p->exp_libm = d.exp_libm;
 }
 
 void* orc_ndt_create(const orc_ndt_params* p) {
@@ -43,6 +44,7 @@ void* orc_ndt_create(const orc_ndt_params* p) {
   d.mt_max_step_iterations = p->mt_max_step_iterations;
   d.num_threads = p->num_threads;
   d.fix_hessian_d1 = p->fix_hessian_d1;
+  d.exp_libm = p->exp_libm;
   return new NdtCpu(d);
 }
 void orc_ndt_destroy(void* h) { delete static_cast<NdtCpu*>(h); }

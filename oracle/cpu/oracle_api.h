@@ -10,7 +10,7 @@ extern "C" {
 
 typedef struct orc_ndt_params {
   double resolution, step_size, outlier_ratio, transformation_epsilon, min_covar_eigvalue_mult;
-  int32_t max_iterations, search_method, min_points_per_voxel, line_search, mt_max_step_iterations, num_threads, fix_hessian_d1;
+  int32_t max_iterations, search_method, min_points_per_voxel, line_search, mt_max_step_iterations, num_threads, fix_hessian_d1, exp_libm;
 } orc_ndt_params;
 
 typedef struct orc_result {

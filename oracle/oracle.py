@@ -38,7 +38,7 @@ class NdtParams(C.Structure):
                 ("transformation_epsilon", C.c_double), ("min_covar_eigvalue_mult", C.c_double),
                 ("max_iterations", C.c_int32), ("search_method", C.c_int32), ("min_points_per_voxel", C.c_int32),
                 ("line_search", C.c_int32), ("mt_max_step_iterations", C.c_int32), ("num_threads", C.c_int32),
-                ("fix_hessian_d1", C.c_int32)]
+                ("fix_hessian_d1", C.c_int32), ("exp_libm", C.c_int32)]
 
 
 class GicpParams(C.Structure):
@@ -103,7 +103,7 @@ class NdtOracle:
 
     def __init__(self, resolution=1.0, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
                  step_size=0.1, outlier_ratio=0.55, line_search=1, num_threads=0, min_points_per_voxel=6,
-                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False):
+                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False, exp_libm=0):
         L = lib(perturbed)
         self._L = L
         p = NdtParams()
@@ -120,6 +120,7 @@ class NdtOracle:
         p.min_covar_eigvalue_mult = min_covar_eigvalue_mult
         p.mt_max_step_iterations = mt_max_step_iterations
         p.fix_hessian_d1 = fix_hessian_d1
+        p.exp_libm = exp_libm   # 1: the host libm's expf instead of the platform-independent det_expf (a <= 1 ulp perturbation)
         self.params = p
         self.max_iterations = max_iterations
         self._h = C.c_void_p(L.orc_ndt_create(C.byref(p)))

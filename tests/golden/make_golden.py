@@ -87,4 +87,5 @@ def main_vgicp():
 if __name__ == "__main__":
     if "--vgicp-only" not in sys.argv:
         main()
-    main_vgicp()
+    if "--registration-only" not in sys.argv:
+        main_vgicp()
