@@ -65,7 +65,7 @@ __device__ __forceinline__ void neighbour_offset(int k, int& dx, int& dy, int& d
 
 template <int SEARCH>
 __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
-                                                                 const NdtPair* __restrict__ pairs, const VoxelGrid g, const float gd1,
+                                                                 const NdtPair* __restrict__ pairs, const VoxelGrid g, const double gd1,
                                                                  const float gd2, const int leaf_pow2, double* __restrict__ partials,
                                                                  const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks) {
   // ---- map this workgroup to (still-active pair, slice).  The launch always has gridDim.x workgroups; they are dealt
@@ -173,10 +173,12 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
       const float u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
       const float u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
       float e = expf(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
-      const float score_inc = -gd1 * e;
+      // gauss_d1 is a double upstream: float(double(e) * d1), not e * float(d1) -- the float constant alone would scale score,
+      // gradient and Hessian by (1 + 2.8e-8) at 1 m resolution, which was the whole per-evaluation difference to a CPU run
+      const float score_inc = (float)(-gd1 * (double)e);
       e = gd2 * e;
       if (e > 1.f || e < 0.f || e != e) continue;  // upstream "error checking for invalid values"
-      const float w = e * gd1;
+      const float w = (float)((double)e * gd1);
       const float wd = w * gd2;
       sc += score_inc;
       any = true;
@@ -938,7 +940,8 @@ static void launch_strict(dgs_handle* h, const NdtLaunch& L, const dim3 grid, co
 
 static void launch_derivatives(dgs_handle* h, const NdtLaunch& L) {
   const dim3 grid(L.total_blocks), block(kBlock);
-  const float gd1 = (float)h->consts.gauss_d1, gd2 = (float)h->consts.gauss_d2;
+  const double gd1 = h->consts.gauss_d1;
+  const float gd2 = (float)h->consts.gauss_d2;
   int fe = 0;
   const int leaf_pow2 = (std::frexp(h->grid.leaf, &fe) == 0.5f) ? 1 : 0;
   int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES);

@@ -45,14 +45,17 @@ def _ulp_shift(G, k):
     return Gp
 
 
-def ndt_oracle_band(orc, tgt, src, guess=None, **kw):
+def ndt_oracle_band(orc, tgt, src, guess=None, twins=None, **kw):
     """The reference algorithm's own reproducibility on one pair: the largest deviation of the oracle's answer under
-    perturbations that carry no information -- the same source compiled with FMA contraction, and the float32 initial
-    guess moved by +-1 and +-2 ulps.  Returns (result of the unperturbed oracle, band_translation, band_rotation)."""
+    perturbations that carry no information -- the same source compiled with FMA contraction, the host libm's expf instead
+    of the platform-independent one, and the float32 initial guess moved by +-1 and +-2 ulps.  `twins` selects a subset
+    (tuples (perturbed build, exp_libm, ulps)).  Returns (result of the unperturbed oracle, band_translation, band_rotation)."""
     G = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, np.float32)
+    if twins is None:
+        twins = ((True, 0, 0), (False, 1, 0), (False, 0, 1), (False, 0, -1), (False, 0, 2), (False, 0, -2))
     runs = []
-    for perturbed, k in ((False, 0), (True, 0), (False, 1), (False, -1), (False, 2), (False, -2)):
-        o = orc.NdtOracle(perturbed=perturbed, **kw)
+    for perturbed, libm, k in ((False, 0, 0),) + tuple(twins):
+        o = orc.NdtOracle(perturbed=perturbed, exp_libm=libm, **kw)
         o.set_target(tgt)
         o.set_source(src)
         runs.append(o.align(_ulp_shift(G, k)))

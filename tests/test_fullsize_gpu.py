@@ -1,11 +1,13 @@
 """-m gpu parity at BASELINE.json's full sizes, plus size-independent properties and the committed goldens.
 
-Tolerance (north_star): final pose within 1e-4 m / 1e-5 rad of the reference CPU path.  NDT's per-point math is float
-(as upstream) and its Newton iteration amplifies rounding on ill-conditioned pairs, so every comparison is made beside
-the oracle's OWN band: the distance between the oracle and the same source compiled with FMA contraction (a <= 1 ulp
-perturbation, oracle/_build/liboracle_fma.so) and under +-1 / +-2 float32 ulps on the initial guess (tests/helpers.py).  A pair counts as well-conditioned when that band is inside the
-tolerance; there the HIP path must be inside the tolerance too; elsewhere parity is asserted per evaluation
-(score / gradient / Hessian at the oracle's own iterates), which is what the kernels control."""
+Tolerance (north_star): final pose within 1e-4 m / 1e-5 rad of the reference CPU path.
+* In upstream operation order (dgs_params.ndt_strict_order >= 1) the final transform EQUALS the oracle's on every pair,
+  unconditionally: tests/test_strict_gpu.py, and the loop-closure test below.
+* The default (fast) order re-associates the float per-point math (1/3 of the flops).  NDT's damped Newton iteration with its
+  loose stop amplifies float rounding on ill-conditioned pairs -- the oracle itself moves by more than the tolerance there when
+  it is compiled with FMA contraction, uses the host libm's expf, or its float32 guess moves by an ulp (tests/helpers.py).  The
+  fast order is therefore asserted per evaluation everywhere (score / gradient / Hessian at the oracle's own iterates) and on
+  the final pose wherever the oracle's own band is inside the tolerance."""
 import os
 
 import numpy as np
@@ -45,7 +47,8 @@ def test_cfg2_kitti_pair_ndt(oracle_lib):
     ro, bt, br = ndt_oracle_band(oracle_lib, tgt, src, resolution=1.0)
     assert r.hasConverged() == ro["converged"]
     assert r.last_result.iterations == ro["iterations"] and r.last_result.evaluations == ro["evaluations"]
-    _check_against_band(r.getFinalTransformation(), ro["T"], bt, br)
+    et, er = pose_error(r.getFinalTransformation(), ro["T"])
+    assert et <= TOL_TRANS and er <= TOL_ROT, (et, er, bt, br)
     # from the identity guess NDT at 1 m resolution locks y / yaw but not the 1 m along-street offset (the ground rings
     # carry most points and do not constrain x); with an odometry-like prediction it reaches the ground truth
     guess = Tgt.copy()
@@ -121,10 +124,19 @@ def test_cfg4_loop_batch_sharded_api_matches_sequential(oracle_lib):
         est[:2, :2] = G[:2, :2]
         est[:2, 2] = G[:2, 3]
         cands.append(KeyFrame(sources[c], est, 0.0, c + 1))
-    dg = LoopDetector({"fitness_score_thresh": 1e9}, registration=_reg(ndt_resolution=1.0))
     dc = LoopDetector({"fitness_score_thresh": 1e9}, registration=OracleEngine("NDT_OMP", resolution=1.0))
-    lg, lc = dg.matching(cands, new), dc.matching(cands, new)
-    well = 0
+    lc = dc.matching(cands, new)
+    # ---- upstream operation order: every record equals the sequential reference loop's, and so does the chosen loop
+    ds = LoopDetector({"fitness_score_thresh": 1e9}, registration=_reg(ndt_resolution=1.0, ndt_strict_order=1))
+    ls = ds.matching(cands, new)
+    for c in range(6):
+        assert (ds.last_records[c, 1] > 0.5) == (dc.last_records[c, 1] > 0.5)
+        assert np.array_equal(ds.last_records[c, 4:20].astype(np.float32), dc.last_records[c, 4:20].astype(np.float32)), c
+        assert abs(ds.last_records[c, 2] - dc.last_records[c, 2]) <= 1e-11 * dc.last_records[c, 2]
+    assert (ls is None) == (lc is None) and (ls is None or (ls.key2.id == lc.key2.id and np.array_equal(ls.relative_pose, lc.relative_pose)))
+    # ---- default (fast) order
+    dg = LoopDetector({"fitness_score_thresh": 1e9}, registration=_reg(ndt_resolution=1.0))
+    lg = dg.matching(cands, new)
     r = _reg(ndt_resolution=1.0)
     r.setInputTarget(tgt)
     o = oracle_lib.NdtOracle(resolution=1.0)
@@ -132,7 +144,7 @@ def test_cfg4_loop_batch_sharded_api_matches_sequential(oracle_lib):
     for c in range(6):
         assert (dg.last_records[c, 1] > 0.5) == (dc.last_records[c, 1] > 0.5)
         ro, bt, br = ndt_oracle_band(oracle_lib, tgt, sources[c], guesses[c], resolution=1.0)
-        well += int(_check_against_band(dg.last_records[c, 4:20].reshape(4, 4), dc.last_records[c, 4:20].reshape(4, 4), bt, br))
+        _check_against_band(dg.last_records[c, 4:20].reshape(4, 4), dc.last_records[c, 4:20].reshape(4, 4), bt, br)
         # whatever the conditioning, every evaluation along the oracle's own trajectory agrees tightly
         r.setInputSource(sources[c])
         o.set_source(sources[c])
@@ -140,7 +152,6 @@ def test_cfg4_loop_batch_sharded_api_matches_sequential(oracle_lib):
             so, go, Ho = o.derivatives(p)
             sg, gg, Hg = r.ndt_derivatives(p)
             assert abs(so - sg) <= 1e-6 * abs(so) and np.abs(go - gg).max() <= 5e-6 * np.abs(go).max() and np.abs(Ho - Hg).max() <= 5e-6 * np.abs(Ho).max()
-    assert well >= 2
     # the arg-min agrees whenever the two best fitness scores are separated by more than the pose noise can move them
     fit = np.where(dc.last_records[:, 1] > 0.5, dc.last_records[:, 2], np.inf)
     order = np.argsort(fit)
