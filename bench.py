@@ -201,6 +201,10 @@ def main():
             from oracle import oracle as orc
             ncpu = orc.max_threads()
 
+            # the guesses the detector handed to align(): loop_detector.hpp:139-143 rebuilds them from the 2-D keyframe estimates, which
+            # moves some entries of synth's float32 matrices by an ulp -- the oracle must start from the very same matrices
+            guesses_used = LoopDetector.guesses_for(new_kf, cands)
+
             def cpu_run(threads, budget, limit=P, fitness=False):
                 o = orc.NdtOracle(resolution=args.resolution, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
                                   num_threads=threads)
@@ -210,7 +214,7 @@ def main():
                 while len(Ts) < limit:
                     c = len(Ts)
                     o.set_source(sources[c])
-                    Ts.append(o.align(guesses[c])["T"])
+                    Ts.append(o.align(guesses_used[c])["T"])
                     if fitness:   # pcl::Registration::getFitnessScore: one thread, one kd-tree query per source point
                         tf0 = time.perf_counter()
                         orc.fitness_score(tgt, sources[c], Ts[-1])

@@ -49,10 +49,12 @@ class Result(C.Structure):
 SYMBOLS = [
     "dgs_params_init", "dgs_create", "dgs_destroy", "dgs_last_error", "dgs_abi_version", "dgs_set_stream",
     "dgs_synchronize", "dgs_set_input_target", "dgs_set_input_source", "dgs_align", "dgs_get_fitness_score",
-    "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_align_batch", "dgs_calc_fitness_score", "dgs_voxel_grid_filter", "dgs_cloud_create", "dgs_cloud_destroy", "dgs_cloud_size",
+    "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_nn_fitness_distances", "dgs_align_batch", "dgs_calc_fitness_score", "dgs_voxel_grid_filter", "dgs_cloud_create", "dgs_cloud_destroy", "dgs_cloud_size",
     "dgs_set_input_target_cloud", "dgs_set_input_source_cloud", "dgs_align_batch_clouds", "dgs_profile_enable",
     "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_get_voxels",
     "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize", "dgs_vgicp_get_voxels",
+    "dgs_group_create", "dgs_group_destroy", "dgs_group_last_error", "dgs_group_size", "dgs_group_uses_rccl", "dgs_group_last_gather_used_rccl",
+    "dgs_group_member", "dgs_group_set_input_target", "dgs_group_align_batch",
 ]
 
 _lib = None
@@ -83,6 +85,7 @@ def load():
     lib.dgs_get_fitness_score.argtypes = [C.c_void_p, C.c_double, P(C.c_double)]
     lib.dgs_get_inlier_fraction.argtypes = [C.c_void_p, C.c_double, P(C.c_double)]
     lib.dgs_nearest_search_target.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.dgs_nn_fitness_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.dgs_align_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_double, P(Result)]
     lib.dgs_calc_fitness_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double, P(C.c_double)]
@@ -105,5 +108,18 @@ def load():
     lib.dgs_gicp_get_covariances.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.dgs_gicp_linearize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, P(C.c_double), C.c_void_p, C.c_void_p]
     lib.dgs_vgicp_get_voxels.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int64)]
+    lib.dgs_group_create.argtypes = [P(Params), C.c_void_p, C.c_int32, P(C.c_void_p)]
+    lib.dgs_group_destroy.argtypes = [C.c_void_p]
+    lib.dgs_group_destroy.restype = None
+    lib.dgs_group_last_error.argtypes = [C.c_void_p]
+    lib.dgs_group_last_error.restype = C.c_char_p
+    lib.dgs_group_size.argtypes = [C.c_void_p]
+    lib.dgs_group_uses_rccl.argtypes = [C.c_void_p]
+    lib.dgs_group_last_gather_used_rccl.argtypes = [C.c_void_p]
+    lib.dgs_group_member.argtypes = [C.c_void_p, C.c_int32]
+    lib.dgs_group_member.restype = C.c_void_p
+    lib.dgs_group_set_input_target.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.dgs_group_align_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, P(Result), P(C.c_int32),
+                                          P(C.c_double)]
     _lib = lib
     return lib

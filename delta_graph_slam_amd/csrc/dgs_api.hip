@@ -4,6 +4,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -203,6 +204,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   }
   h->device = dev;
   h->own_stream = true;
+  if (const char* e = std::getenv("DGS_NN_GRID")) h->use_grid = std::atoi(e) != 0;
   std::memset(h->final_T, 0, sizeof(h->final_T));
   h->final_T[0] = h->final_T[5] = h->final_T[10] = h->final_T[15] = 1.f;
   *out = h;
@@ -231,7 +233,7 @@ void dgs_destroy(dgs_handle* h) {
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
   h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
-  h->nn_partials.release(); h->scratch_cloud.release(); h->strict_rows.release(); h->strict_totals.release();
+  h->nn_partials.release(); h->scratch_cloud.release(); h->strict_rows.release(); h->strict_totals.release(); h->tgt_grid.release(); h->aux_grid.release();
   h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_out.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
   h->aux_bvh.keys.release(); h->aux_bvh.keys_alt.release(); h->aux_bvh.vals.release(); h->aux_bvh.vals_alt.release();
   h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
@@ -273,6 +275,7 @@ int dgs_set_input_target(dgs_handle* h, const float* xyz16, int64_t n, int32_t o
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_target = false;
   h->vmap_valid = false;
+  h->tgt_grid.valid = false;
   unbind(h, h->tgt_cloud);
   h->tgt = &h->own_target;
   h->tgt->invalidate();
@@ -331,7 +334,7 @@ int dgs_cloud_create(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_de
 void dgs_cloud_destroy(dgs_cloud* c) {
   if (!c) return;
   for (dgs_handle* h : c->users) {  // handles still pointing here fall back to "no input set"
-    if (h->tgt_cloud == c) { h->tgt_cloud = nullptr; h->tgt = &h->own_target; h->nt = 0; h->have_target = false; }
+    if (h->tgt_cloud == c) { h->tgt_cloud = nullptr; h->tgt = &h->own_target; h->nt = 0; h->have_target = false; h->tgt_grid.valid = false; }
     if (h->src_cloud == c) { h->src_cloud = nullptr; h->src = &h->own_source; h->ns = 0; h->have_source = false; }
   }
   (void)hipSetDevice(c->device);
@@ -348,6 +351,7 @@ int dgs_set_input_target_cloud(dgs_handle* h, dgs_cloud* c) {
   if (set_device(h)) return DGS_ERR_HIP;
   h->have_target = false;
   h->vmap_valid = false;
+  h->tgt_grid.valid = false;
   bind(h, h->tgt_cloud, c);
   h->tgt = &c->st;
   h->nt = c->st.n;
@@ -472,6 +476,32 @@ int dgs_nearest_search_target(dgs_handle* h, const float* queries, int64_t m, in
   return rc;
 }
 
+int dgs_nn_fitness_distances(dgs_handle* h, const float* queries, int64_t m, int32_t on_device, float* sq_dists) {
+  if (!h || m < 0 || (m > 0 && (!queries || !sq_dists))) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
+  if (!h->use_grid) return DGS_ERR_UNSUPPORTED;
+  if (m == 0) return DGS_OK;
+  if (side_join(h) != DGS_OK) return DGS_ERR_HIP;
+  int rc = ensure_target_index(h);
+  if (rc) return rc;
+  const float4* dq = reinterpret_cast<const float4*>(queries);
+  float* dsq = sq_dists;
+  DevBuf<float4> q;
+  DevBuf<float> bd;
+  if (!on_device) {
+    if (q.reserve(m) != hipSuccess || bd.reserve(m) != hipSuccess) { h->err = "hipMalloc failed"; rc = DGS_ERR_HIP; }
+    if (!rc && hipMemcpyAsync(q.ptr, queries, (size_t)m * sizeof(float4), hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "hipMemcpyAsync failed"; rc = DGS_ERR_HIP; }
+    dq = q.ptr; dsq = bd.ptr;
+  }
+  if (!rc) rc = nn_grid_search(h, h->tgt_grid, h->tgt->bvh, dq, m, dsq);
+  if (!rc && !on_device && hipMemcpyAsync(sq_dists, dsq, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) { h->err = "hipMemcpyAsync failed"; rc = DGS_ERR_HIP; }
+  (void)hipStreamSynchronize(h->stream);
+  q.release(); bd.release();
+  return rc;
+}
+
 // FAST_GICP over a batch of sources (loop_detector.hpp:137-156): batched align, then one fitness launch for all candidates
 static int gicp_batch(dgs_handle* h, int n, CloudState* const* cs, const float* guesses16, int compute_fitness, double fitness_max_range,
                       dgs_result* results) {
@@ -551,11 +581,11 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
   }
   // the fitness pass needs the target's NN index only after the last iteration: build it on the side stream meanwhile
   // (a dozen tiny launches, 0.15 ms on the critical path otherwise); kernels timed one by one stay on one stream
-  if (compute_fitness && !h->tgt->bvh.valid && !h->prof.enabled) {
+  if (compute_fitness && (!h->tgt->bvh.valid || (h->use_grid && !h->tgt_grid.valid)) && !h->prof.enabled) {
     int rs = side_fork(h);
-    if (rs == DGS_OK) rs = bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt, h->side_stream);
+    if (rs == DGS_OK) rs = ensure_target_index(h, h->side_stream);
     if (rs == DGS_OK && hipEventRecord(h->ev_join, h->side_stream) == hipSuccess) h->side_pending = true;
-    if (rs != DGS_OK) { (void)hipStreamSynchronize(h->side_stream); h->tgt->bvh.valid = false; return rs; }
+    if (rs != DGS_OK) { (void)hipStreamSynchronize(h->side_stream); h->tgt->bvh.valid = false; h->tgt_grid.valid = false; return rs; }
   }
   int rc = ndt_align_pairs(h, n, ptrs.data(), sz.data(), guesses16, results);
   if (side_join(h) != DGS_OK && rc == DGS_OK) rc = DGS_ERR_HIP;  // whatever happened above, nothing stays pending
@@ -677,6 +707,7 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const
   int rc = upload_cloud(h, h->aux_cloud1, cloud1, n1, on_device);
   if (rc == DGS_OK) rc = upload_cloud(h, h->aux_cloud2, cloud2, n2, on_device);
   if (rc == DGS_OK) rc = bvh_build(h, h->aux_bvh, h->aux_cloud1.ptr, n1);
+  if (rc == DGS_OK && h->use_grid) rc = nn_grid_build(h, h->aux_grid, h->aux_bvh, h->aux_cloud1.ptr, n1);
   if (rc != DGS_OK) return rc;
   // stage pointer / size / transform exactly like the single-pair fitness path, but against the auxiliary index
   hipStream_t st = h->stream;
@@ -695,7 +726,7 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const
   DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, base + 64, sizeof(float) * 16, hipMemcpyHostToDevice, st));
   double sum = 0;
   int64_t cnt = 0, inl = 0;
-  rc = nn_fitness_batch_on(h, h->aux_bvh, 1, h->src_ptrs.ptr, h->src_sizes.ptr, ni, reinterpret_cast<const float*>(h->inits.ptr), 64, max_range, 0.0,
+  rc = nn_fitness_batch_on(h, h->aux_bvh, (h->use_grid && h->aux_grid.valid) ? &h->aux_grid : nullptr, 1, h->src_ptrs.ptr, h->src_sizes.ptr, ni, reinterpret_cast<const float*>(h->inits.ptr), 64, max_range, 0.0,
                            &sum, &cnt, &inl);
   if (rc != DGS_OK) return rc;
   *score = cnt > 0 ? sum / (double)cnt : DBL_MAX;

@@ -30,6 +30,45 @@ struct Bvh {
   bool valid = false;
 };
 
+// Sparse 64-ary voxel hierarchy over a target cloud for one-lane-per-query exact 1-NN distances (nn_grid.hip).  Belongs to a
+// handle (rebuilt at every setInputTarget: one sort of the target plus a few passes), not to a cached cloud: the dense tables
+// (one entry per COARSE cell) are a fixed 8 MB budget per handle whatever the cloud.
+constexpr int64_t kNnGridL2Cells = 8192;   // L2 cells (16 x 16 x 16 fine cells each) the tables are sized for
+struct NnGridParams {   // decided on the device (grid_params_kernel): no host round trip between the tree build and this one
+  float org[3];         // corner of fine cell (0, 0, 0)
+  float c, inv_c;       // fine cell size; a coarse cell is 4 x 4 x 4 fine cells, an L2 cell 4 x 4 x 4 coarse cells
+  int n2[3];            // L2 cells per axis
+  int n;
+};
+struct __attribute__((aligned(16))) NnCoarse {
+  unsigned long long mask;   // occupied fine cells, bit x | y << 2 | z << 4
+  int base;                  // rank (in key order) of the first occupied fine cell: index into cstart
+  int pad;
+};
+struct NnGrid {
+  DevBuf<float4> sorted;                   // target points ordered by (L2 cell, coarse sub-cell, fine sub-cell)
+  DevBuf<NnCoarse> coarse;                 // [L2 cell * 64 + coarse sub-cell]
+  DevBuf<unsigned long long> occ2;         // [L2 cell] occupied coarse cells
+  DevBuf<int> cstart;                      // first point of every occupied fine cell, in key order; entry [runs] = n
+  DevBuf<uint32_t> keys, keys_alt, vals, vals_alt, run_keys;   // run_keys is kept: the next build clears exactly those cells
+  DevBuf<int> run_counts, scalars;         // scalars[0] = number of runs
+  DevBuf<NnGridParams> params;
+  DevBuf<unsigned> hist;
+  // query side: squared NN distance per query of a batch, the two queues of still-open queries {query number, best so far}
+  DevBuf<float> dist, q_best;
+  DevBuf<unsigned> q_items;
+  DevBuf<int> q_count;
+  DevBuf<double> hook;   // 128-byte staging block of the test hook
+  int64_t n = 0, n_prev = 0;
+  bool valid = false;
+  void release() {
+    sorted.release(); coarse.release(); occ2.release(); cstart.release(); keys.release(); keys_alt.release(); vals.release(); vals_alt.release();
+    run_keys.release(); run_counts.release(); scalars.release(); params.release(); hist.release();
+    dist.release(); q_best.release(); q_items.release(); q_count.release(); hook.release();
+    n = n_prev = 0; valid = false;
+  }
+};
+
 // A cloud resident in HBM with everything derived from the points alone: the exact-NN index and (GICP) the regularised
 // k-NN covariances.  Owned by a handle (setInputTarget / setInputSource copies) or by a dgs_cloud object that outlives
 // many registrations (keyframe clouds of the loop detector).
@@ -120,6 +159,8 @@ struct dgs_handle {
 
   dgs::DevBuf<double> nn_partials;
   dgs::DevBuf<float4> scratch_cloud;
+  dgs::NnGrid tgt_grid, aux_grid;   // fitness-pass index over the current target / over cloud1 of dgs_calc_fitness_score
+  bool use_grid = false;            // DGS_NN_GRID=1 in the environment at dgs_create: grid passes in front of the tree walk (A/B measurements)
 
   // ---- calc_fitness_score between two arbitrary clouds (InformationMatrixCalculator): own buffers, the registration's
   // target / source / result are left untouched
@@ -172,9 +213,15 @@ int nn_fitness(dgs_handle* h, const float4* src, int64_t n, const float* T16, do
 // batched: device arrays of source pointers / sizes, device transforms (column-major 16 floats every T_stride_bytes)
 int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
-int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
+int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
                         const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
+int ensure_target_index(dgs_handle* h, hipStream_t st = nullptr);   // tree + grid over the current target (no-op when both are valid)
+// nn_grid.hip
+int nn_grid_build(dgs_handle* h, NnGrid& G, const Bvh& bvh, const float4* pts, int64_t n, hipStream_t st = nullptr);
+int nn_grid_launch_fitness(dgs_handle* h, NnGrid& G, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_n, const float* d_T,
+                           size_t T_stride_bytes, float max_range, float inlier_sq, double* partial, int bpp);
+int nn_grid_search(dgs_handle* h, NnGrid& G, const Bvh& index, const float4* queries, int64_t m, float* d_sq);
 // gicp.hip
 int vgicp_build_map(dgs_handle* h);  // vgicp_voxel.hip: needs the target covariances
 int vgicp_voxels(dgs_handle* h, int64_t capacity, int32_t* coord3, int32_t* counts, double* mean3, double* cov9, int64_t* n_voxels);

@@ -255,6 +255,14 @@ static int ensure_target_bvh(dgs_handle* h) {
   return bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt);
 }
 
+// tree + (fitness pass) grid over the current target, on `st` (default: the handle's stream)
+int ensure_target_index(dgs_handle* h, hipStream_t st) {
+  int rc = DGS_OK;
+  if (!h->tgt->bvh.valid) rc = bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt, st);
+  if (rc == DGS_OK && h->use_grid && !h->tgt_grid.valid) rc = nn_grid_build(h, h->tgt_grid, h->tgt->bvh, h->tgt->pts.ptr, h->nt, st);
+  return rc;
+}
+
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq) {
   int rc = ensure_target_bvh(h);
   if (rc) return rc;
@@ -272,15 +280,18 @@ int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, f
 int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
   int rc = ensure_target_bvh(h);
+  if (rc == DGS_OK) rc = ensure_target_index(h);
   if (rc) return rc;
-  return nn_fitness_batch_on(h, h->tgt->bvh, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, max_range, inlier_sq, sums, counts, inliers);
+  return nn_fitness_batch_on(h, h->tgt->bvh, h->tgt_grid.valid ? &h->tgt_grid : nullptr, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, max_range,
+                             inlier_sq, sums, counts, inliers);
 }
 
-int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
-                        size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
+int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
+                        const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
   hipStream_t st = h->stream;
   const BvhView v = make_bvh_view(index);
-  const int full = std::max(1, (int)(((int64_t)max_size * 8 + kBlock - 1) / kBlock));  // one query per 8 lanes
+  // tree walk: one query per 8 lanes; grid: one query per lane
+  const int full = std::max(1, (int)(((int64_t)max_size * (grid ? 1 : 8) + kBlock - 1) / kBlock));
   const int bpp = std::max(1, std::min(full, std::max(64, 8192 / std::max(1, n_pairs))));
   DGS_HIP_TRY(h, h->nn_partials.reserve((size_t)n_pairs * bpp * 4 + (size_t)n_pairs * 4));
   double* d_out = h->nn_partials.ptr + (size_t)n_pairs * bpp * 4;
@@ -289,8 +300,12 @@ int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, int n_pairs, const floa
   const float mr = (max_range >= (double)FLT_MAX) ? FLT_MAX : (float)max_range;
   const float iq = (inlier_sq >= (double)FLT_MAX) ? FLT_MAX : (float)inlier_sq;
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
-  hipLaunchKernelGGL(nn_fitness_kernel, dim3(bpp, n_pairs), dim3(kBlock), 0, st, v, d_src_ptrs, d_sizes, d_T, T_stride_bytes, mr, iq,
-                     h->nn_partials.ptr, bpp);
+  if (grid) {
+    const int rg = nn_grid_launch_fitness(h, *grid, index, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, mr, iq, h->nn_partials.ptr, bpp);
+    if (rg) return rg;
+  } else
+    hipLaunchKernelGGL(nn_fitness_kernel, dim3(bpp, n_pairs), dim3(kBlock), 0, st, v, d_src_ptrs, d_sizes, d_T, T_stride_bytes, mr, iq,
+                       h->nn_partials.ptr, bpp);
   prof_end(h, DGS_K_NN_SEARCH, slot);
   hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(n_pairs), dim3(kWave), 0, st, h->nn_partials.ptr, bpp, n_pairs, d_out);
   double* hout = reinterpret_cast<double*>(reinterpret_cast<char*>(h->pinned) + 4096);

@@ -160,7 +160,9 @@ __device__ __forceinline__ void nn_query_group_t(const BvhView& b, float x, floa
   const int last_sh = 8 * (b.depth - 1);
   PT pend = 0;
   bool fresh = true;
-  bool done = !alive;
+  // a NaN coordinate makes every box distance compare as 0 (max(NaN, 0) = 0), the inverted boxes of empty slots included, and
+  // the walk would run off the end of the point array: such a query has no neighbour, it only follows the control flow
+  bool done = !alive || !(x == x && y == y && z == z);
 #ifdef DGS_NN_STEPS
   int n_nodes = 0, n_leaves = 0, n_wasted = 0;
 #endif
@@ -311,7 +313,7 @@ __device__ __forceinline__ void knn_query_group_t(const BvhView& b, float x, flo
   const int last_sh = 8 * (b.depth - 1);
   PT pend = 0;
   bool fresh = true;
-  bool done = !alive;
+  bool done = !alive || !(x == x && y == y && z == z);   // NaN query: see nn_query_group_t
   while (__any(!done)) {
     if (!done) {
       const unsigned ofs = (unsigned)node * kFan + sub;

@@ -24,7 +24,7 @@ try:  # torch is plumbing only: device memory + streams
 except Exception:  # pragma: no cover
     torch = None
 
-__all__ = ["Registration", "DeviceCloud", "select_registration_method", "DgsError"]
+__all__ = ["Registration", "RegistrationGroup", "DeviceCloud", "select_registration_method", "DgsError"]
 DgsError = L.DgsError
 
 
@@ -212,6 +212,15 @@ class Registration:
         self._check(self._lib.dgs_nearest_search_target(self._h, ptr, m, 0, idx.ctypes.data_as(C.c_void_p), sq.ctypes.data_as(C.c_void_p)))
         return idx, sq
 
+    def nn_fitness_distances(self, queries):
+        """Test hook: squared 1-NN distances through the fitness pass's grid index (must equal nearestKSearch's)."""
+        ptr, m, dev, keep = _cloud_ptr(queries)
+        if dev:
+            raise ValueError("host queries only in the Python mirror")
+        sq = np.empty(m, dtype=np.float32)
+        self._check(self._lib.dgs_nn_fitness_distances(self._h, ptr, m, 0, sq.ctypes.data_as(C.c_void_p)))
+        return sq
+
     def calc_fitness_score(self, cloud1, cloud2, relpose=None, max_range: float = 1.7976931348623157e308) -> float:
         """InformationMatrixCalculator::calc_fitness_score (information_matrix_calculator.cpp:77-108) on the device."""
         p1, n1, d1, k1 = _cloud_ptr(cloud1)
@@ -373,6 +382,110 @@ class Registration:
         keep = keys >= 0
         o = np.argsort(keys[keep])
         return dict(keys=keys[keep][o], counts=counts[keep][o], valid=valid[keep][o].astype(bool), mean=mean[keep][o], icov=icov[keep][o])
+
+
+class RegistrationGroup:
+    """dgs_group (include/dgs_reg.h): the candidate loop of LoopDetector::matching (loop_detector.hpp:137-156) sharded over
+    several GPUs of ONE process -- candidate c goes to device c mod G, the result records come back through an RCCL all-gather
+    in original candidate order.  Offers the batch surface LoopDetector drives (setInputTarget / align_batch[_records]), so a
+    LoopDetector(registration=RegistrationGroup(...)) is the single-process counterpart of the one-process-per-GPU sharding."""
+
+    def __init__(self, method: str = "NDT_OMP", devices=(0,), **params):
+        lib = L.load()
+        self._lib = lib
+        exact = {"NDT_OMP": L.METHOD_NDT, "NDT_HIP": L.METHOD_NDT, "FAST_GICP": L.METHOD_GICP, "FAST_GICP_HIP": L.METHOD_GICP,
+                 "FAST_VGICP": L.METHOD_VGICP, "FAST_VGICP_HIP": L.METHOD_VGICP}
+        if method not in exact:
+            raise NotImplementedError(f"registration_method {method!r} is not served by the HIP back-ends")
+        p = L.Params()
+        rc = lib.dgs_params_init(C.byref(p), exact[method])
+        if rc:
+            raise DgsError(rc, "dgs_params_init")
+        for k, v in params.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown registration parameter {k!r}")
+            setattr(p, k, v)
+        self.devices = [int(d) for d in devices]
+        dv = (C.c_int32 * len(self.devices))(*self.devices)
+        self._g = C.c_void_p()
+        rc = lib.dgs_group_create(C.byref(p), dv, len(self.devices), C.byref(self._g))
+        if rc:
+            raise DgsError(rc, "dgs_group_create failed (this package has no CPU fallback): " + (lib.dgs_last_error(None) or b"").decode())
+        self.best_index = -1
+        self.best_score = float("inf")
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g.value:
+            self._lib.dgs_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise DgsError(rc, (self._lib.dgs_group_last_error(self._g) or b"").decode())
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self._lib.dgs_group_uses_rccl(self._g))
+
+    @property
+    def last_gather_used_rccl(self) -> bool:
+        return bool(self._lib.dgs_group_last_gather_used_rccl(self._g))
+
+    def setInputTarget(self, cloud):
+        ptr, n, dev, keep = _cloud_ptr(cloud)
+        if dev:
+            raise ValueError("a group takes host clouds (KeyFrame::cloud); each member uploads its own copy")
+        self._check(self._lib.dgs_group_set_input_target(self._g, ptr, n))
+
+    def _raw(self, sources, guesses, compute_fitness, fitness_max_range):
+        n = len(sources)
+        g = gp = None
+        if guesses is not None:
+            ga = np.asarray(guesses, dtype=np.float32)
+            g = np.ascontiguousarray(ga.transpose(0, 2, 1).reshape(n, 16)) if ga.ndim == 3 else np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
+            gp = g.ctypes.data_as(C.c_void_p)
+        ptrs = (C.c_void_p * n)()
+        sizes = (C.c_int64 * n)()
+        keep = []
+        for i, s_ in enumerate(sources):
+            ptr, m, dev, k = _cloud_ptr(s_)
+            if dev:
+                raise ValueError("a group takes host clouds")
+            ptrs[i] = ptr.value if ptr.value else 0
+            sizes[i] = m
+            keep.append(k)
+        res = (L.Result * n)()
+        bi = C.c_int32(-1)
+        bs = C.c_double(0)
+        self._check(self._lib.dgs_group_align_batch(self._g, n, ptrs, sizes, gp, 1 if compute_fitness else 0, fitness_max_range, res, C.byref(bi), C.byref(bs)))
+        self.best_index, self.best_score = bi.value, bs.value
+        return res
+
+    def align_batch(self, sources, guesses=None, compute_fitness: bool = True, fitness_max_range: float = 1.7976931348623157e308):
+        if len(sources) == 0:
+            return []
+        res = self._raw(sources, guesses, compute_fitness, fitness_max_range)
+        return [dict(T=_from_col16(r.final_transformation), converged=bool(r.converged), iterations=r.iterations, evaluations=r.evaluations,
+                     status=r.status, score=r.score, fitness=r.fitness) for r in res]
+
+    def align_batch_records(self, sources, guesses=None, compute_fitness: bool = True, fitness_max_range: float = 1.7976931348623157e308):
+        n = len(sources)
+        out = np.full((n, 20), -1.0, dtype=np.float64)
+        if n == 0:
+            return out
+        res = self._raw(sources, guesses, compute_fitness, fitness_max_range)
+        a = np.frombuffer(res, dtype=_RESULT_DTYPE, count=n)
+        out[:, 1] = a["converged"] != 0
+        out[:, 2] = a["fitness"]
+        out[:, 3] = a["status"]
+        out[:, 4:20] = a["T"].reshape(n, 4, 4).transpose(0, 2, 1).reshape(n, 16)
+        return out
 
 
 def select_registration_method(params: dict | None = None, device: int | None = None) -> Registration:

@@ -212,6 +212,30 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1_xyz16, int64_t n1,
 int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
                           int64_t out_capacity, int32_t out_on_device, int64_t* n_out);
 
+/* ---- several GPUs of one process: the candidate loop of LoopDetector::matching sharded across devices -------------------------
+ * The reference runs loop detection inside the nodelet manager process under main_thread_mutex
+ * (/root/reference/apps/delta_graph_slam_nodelet.cpp:797,816; candidate loop loop_detector.hpp:137-156), so the multi-GPU form a
+ * nodelet can link is ONE process driving G devices.  A dgs_group owns one dgs_handle, one host thread and one stream per listed
+ * device.  dgs_group_set_input_target = loop_detector.hpp:124 on every member (G parallel host->device copies).
+ * dgs_group_align_batch deals candidate c to member c mod G, every member runs its share as one dgs_align_batch, the fixed-size
+ * result records are exchanged with ncclAllGather (RCCL over xGMI; communicators from ncclCommInitAll, library loaded with
+ * dlopen) and returned in ORIGINAL candidate order; best_index / best_score (nullable) receive the arg-min of
+ * loop_detector.hpp:126-156 over (converged, fitness) with its tie rule (on an equal score the later candidate wins), -1 /
+ * DBL_MAX when no candidate converged.  The fitness_score_thresh test (:162) stays with the caller.  A group whose device list
+ * names one device twice (a one-GPU rehearsal), or that cannot load RCCL, gathers on the host instead: same results.
+ * Sources and the target are host arrays (KeyFrame::cloud); a group is used by one thread at a time. */
+typedef struct dgs_group dgs_group;
+int dgs_group_create(const dgs_params* params, const int32_t* devices, int32_t n_devices, dgs_group** out); /* params->device is ignored */
+void dgs_group_destroy(dgs_group* g);
+const char* dgs_group_last_error(const dgs_group* g);
+int32_t dgs_group_size(const dgs_group* g);
+int32_t dgs_group_uses_rccl(const dgs_group* g);               /* 1: the group holds RCCL communicators */
+int32_t dgs_group_last_gather_used_rccl(const dgs_group* g);   /* 1: the last dgs_group_align_batch exchanged its records with ncclAllGather */
+dgs_handle* dgs_group_member(dgs_group* g, int32_t k);         /* member k's handle (e.g. for dgs_profile_*); owned by the group */
+int dgs_group_set_input_target(dgs_group* g, const float* xyz16, int64_t n);
+int dgs_group_align_batch(dgs_group* g, int32_t n, const float* const* sources, const int64_t* sizes, const float* guesses16,
+                          int32_t compute_fitness, double fitness_max_range, dgs_result* results, int32_t* best_index, double* best_score);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) ---------------------- */
 enum dgs_kernel_id {
   DGS_K_NDT_DERIVATIVES = 0, DGS_K_NDT_SOLVE = 1, DGS_K_NDT_VOXEL_BUILD = 2, DGS_K_NN_SEARCH = 3,
@@ -236,6 +260,10 @@ int dgs_ndt_get_trajectory(dgs_handle* h, int32_t pair, double* poses6, int32_t*
 /* NDT voxel table dump.  First call with NULL arrays returns the number of occupied voxels in *n. */
 int dgs_ndt_get_voxels(dgs_handle* h, int64_t* n, int64_t* keys, int32_t* counts, int32_t* valid, double* mean3,
                        double* icov9);
+
+/* Test hook: squared exact 1-NN distances of m query points to the target through the index the fitness pass uses (the
+ * one-lane-per-query grid of nn_grid.hip with its tree fallback); must equal dgs_nearest_search_target's sq_dists bit for bit. */
+int dgs_nn_fitness_distances(dgs_handle* h, const float* queries_xyz16, int64_t m, int32_t on_device, float* sq_dists);
 
 /* GICP regularised k-NN covariances (FastGICP::calculate_covariances): which = 0 source, 1 target;
  * cov9 receives 9 doubles (row-major 3x3) per point. */

@@ -2,7 +2,11 @@
 // It exercises the adapter exactly the way the reference does: through pcl::Registration<PointT,PointT>::Ptr returned by a
 // factory fed with rosparam-style values (registrations.cpp), with the odometry call sequence
 // (scan_matching_odometry_nodelet.cpp:180-228) and the loop detector's candidate loop (loop_detector.hpp:124-156).
-// usage: adapter_driver <method> <clouds.bin>   (clouds.bin: int32 n_clouds, then per cloud int32 n + n*4 floats; cloud 0 = target)
+// usage: adapter_driver <method> <clouds.bin> [--devices 0,1,...]
+//   clouds.bin: int32 n_clouds, then per cloud int32 n + n*4 floats; cloud 0 = target.
+//   --devices: additionally run the candidate loop as ONE dgs_group_align_batch over the listed devices (single process, one
+//   host thread + stream per device, RCCL all-gather of the records) and print its records.
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -12,6 +16,17 @@
 #include <dgs/registrations_hip.hpp>
 
 using PointT = pcl::PointXYZ;
+
+// the JSON answer is collected and written as ONE last line: libraries underneath (RCCL at communicator set-up) may print too
+static std::string g_json;
+static void jprintf(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_json += buf;
+}
 
 struct FakeNodeHandle {  // stands in for ros::NodeHandle::param<T>(name, default)
   std::map<std::string, std::string> s;
@@ -57,7 +72,7 @@ int main(int argc, char** argv) {
   registration->setInputTarget(clouds[0]);                              // loop_detector.hpp:124 / smo:180
   double best_score = DBL_MAX;
   int best = -1;
-  std::printf("{\"candidates\": [");
+  jprintf("{\"candidates\": [");
   pcl::PointCloud<PointT>::Ptr aligned(new pcl::PointCloud<PointT>());
   for (size_t c = 1; c < clouds.size(); c++) {
     registration->setInputSource(clouds[c]);                           // :138
@@ -67,14 +82,57 @@ int main(int argc, char** argv) {
     const double score_pcl = registration->getFitnessScore(DBL_MAX);   // the same call through the base pointer (CPU kd-tree)
     const bool conv = registration->hasConverged();
     const Eigen::Matrix4f T = registration->getFinalTransformation();
-    std::printf("%s{\"converged\": %d, \"score\": %.17g, \"score_pcl\": %.17g, \"inliers\": %.17g, \"n_aligned\": %zu, \"T\": [", c > 1 ? ", " : "", conv ? 1 : 0,
+    jprintf("%s{\"converged\": %d, \"score\": %.17g, \"score_pcl\": %.17g, \"inliers\": %.17g, \"n_aligned\": %zu, \"T\": [", c > 1 ? ", " : "", conv ? 1 : 0,
                 score, score_pcl, hip->getInlierFraction(0.25), aligned->size());
-    for (int k = 0; k < 16; k++) std::printf("%s%.9g", k ? ", " : "", T.data()[k]);
-    std::printf("], \"error\": \"%s\"}", hip->lastError().c_str());
+    for (int k = 0; k < 16; k++) jprintf("%s%.9g", k ? ", " : "", T.data()[k]);
+    jprintf("], \"error\": \"%s\"}", hip->lastError().c_str());
     if (!conv || score > best_score) continue;                         // :149
     best_score = score;
     best = (int)c;
   }
-  std::printf("], \"best\": %d}\n", best);
+  jprintf("], \"best\": %d", best);
+  // ---- the same candidate loop, sharded over several devices of this process (what the nodelet links for loop closure)
+  std::vector<int32_t> devices;
+  for (int a = 3; a + 1 < argc; a++)
+    if (std::string(argv[a]) == "--devices")
+      for (const char* p = argv[a + 1]; *p;) {
+        devices.push_back((int32_t)std::strtol(p, const_cast<char**>(&p), 10));
+        if (*p == ',') p++;
+      }
+  if (!devices.empty()) {
+    dgs_params prm;
+    dgs_params_init(&prm, method == "NDT_HIP" ? DGS_METHOD_NDT : method == "FAST_GICP_HIP" ? DGS_METHOD_GICP : DGS_METHOD_VGICP);
+    prm.ndt_resolution = prm.vgicp_resolution = pnh.param<double>("reg_resolution", 0.5);
+    prm.gicp_max_correspondence_distance = pnh.param<double>("reg_max_correspondence_distance", 2.5);
+    dgs_group* group = nullptr;
+    const int rc = dgs_group_create(&prm, devices.data(), (int32_t)devices.size(), &group);
+    jprintf(", \"group\": {\"create\": %d", rc);
+    if (rc == DGS_OK) {
+      const int n = (int)clouds.size() - 1;
+      std::vector<const float*> src(n);
+      std::vector<int64_t> sizes(n);
+      for (int c = 0; c < n; c++) {
+        src[c] = reinterpret_cast<const float*>(clouds[c + 1]->points.data());
+        sizes[c] = (int64_t)clouds[c + 1]->points.size();
+      }
+      std::vector<dgs_result> res(n);
+      int32_t bi = -1;
+      double bs = 0;
+      int rt = dgs_group_set_input_target(group, reinterpret_cast<const float*>(clouds[0]->points.data()), (int64_t)clouds[0]->points.size());  // :124
+      int ra = rt == DGS_OK ? dgs_group_align_batch(group, n, src.data(), sizes.data(), nullptr, 1, DBL_MAX, res.data(), &bi, &bs) : rt;     // :137-156
+      jprintf(", \"status\": %d, \"size\": %d, \"rccl\": %d, \"best\": %d, \"candidates\": [", ra, dgs_group_size(group), dgs_group_last_gather_used_rccl(group),
+                  bi >= 0 ? bi + 1 : -1);
+      for (int c = 0; c < n && ra == DGS_OK; c++) {
+        jprintf("%s{\"converged\": %d, \"score\": %.17g, \"T\": [", c ? ", " : "", res[c].converged, res[c].fitness);
+        for (int k = 0; k < 16; k++) jprintf("%s%.9g", k ? ", " : "", res[c].final_transformation[k]);
+        jprintf("]}");
+      }
+      jprintf("]");
+      dgs_group_destroy(group);
+    }
+    jprintf("}");
+  }
+  jprintf("}");
+  std::printf("\n%s\n", g_json.c_str());
   return 0;
 }

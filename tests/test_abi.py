@@ -105,3 +105,19 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower() or f in (), f"{f} mentions the oracle"
+
+
+def test_group_has_no_cpu_fallback_either():
+    """dgs_group_create fails with DGS_ERR_HIP on a box without a usable device (no member handle can be created)."""
+    import ctypes as C
+    import torch
+    from delta_graph_slam_amd import _lib as L
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    lib = L.load()
+    p = L.Params()
+    assert lib.dgs_params_init(C.byref(p), L.METHOD_NDT) == 0
+    g = C.c_void_p()
+    dv = (C.c_int32 * 2)(0, 1)
+    assert lib.dgs_group_create(C.byref(p), dv, 2, C.byref(g)) == 2 and not g.value
+    assert lib.dgs_group_size(None) == 0 and lib.dgs_group_uses_rccl(None) == 0

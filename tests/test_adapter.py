@@ -24,6 +24,17 @@ def driver(tmp_path_factory):
     return out
 
 
+@pytest.fixture(scope="module")
+def replay(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("adapter") / "odometry_replay")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "tests", "stub_pcl"), "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "odometry_replay.cpp"), "-o", out,
+           os.path.join(ROOT, "delta_graph_slam_amd", "libdgs_reg.so"), "-Wl,-rpath," + os.path.join(ROOT, "delta_graph_slam_amd"),
+           "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return out
+
+
 def _write_clouds(path, clouds):
     with open(path, "wb") as f:
         f.write(struct.pack("i", len(clouds)))
@@ -71,3 +82,56 @@ def test_adapter_matches_python_mirror_on_gpu(driver, tmp_path, method, pyname, 
         assert c["inliers"] == r.getInlierFraction(0.25)
         assert c["n_aligned"] == cloud.shape[0]
     assert res["best"] in (1, 2)
+
+
+def test_odometry_replay_compiles_and_skips_frames_without_a_gpu(replay, tmp_path):
+    import torch
+    clouds, _ = synth.vlp16_stream(n_frames=3)
+    p = str(tmp_path / "s.bin")
+    _write_clouds(p, clouds)
+    lines = [json.loads(ln) for ln in subprocess.check_output([replay, "FAST_GICP_HIP", p, "1.0", "1.0", "1e9"]).decode().splitlines() if ln.startswith("{")]
+    assert [ln["frame"] for ln in lines] == [0, 1, 2] and lines[0]["converged"] == -1
+    if not torch.cuda.is_available():   # no device: "ignore this frame" (smo:222-226): odom stays keyframe_pose * prev_trans = I
+        assert all(ln["converged"] == 0 for ln in lines[1:])
+        assert all(np.allclose(np.array(ln["odom"]).reshape(4, 4).T, np.eye(4)) for ln in lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,pyname,kw", [("FAST_GICP_HIP", "FAST_GICP", dict(gicp_max_correspondence_distance=2.0, transformation_epsilon=0.1)),
+                                              ("NDT_HIP", "NDT_OMP", dict(ndt_resolution=1.0, transformation_epsilon=0.1))])
+def test_cpp_odometry_replay_matches_the_python_mirror_frame_by_frame(replay, tmp_path, method, pyname, kw):
+    """A11 in C++: scan_matching_odometry_nodelet.cpp:173-260 through pcl::Registration::Ptr vs delta_graph_slam_amd/odometry.py."""
+    from delta_graph_slam_amd.odometry import ScanMatchingOdometry
+    from delta_graph_slam_amd.registration import Registration
+    clouds, _ = synth.vlp16_stream(n_frames=40)
+    p = str(tmp_path / "s.bin")
+    _write_clouds(p, clouds)
+    lines = [json.loads(ln) for ln in subprocess.check_output([replay, method, p, "1.0", "1.0", "1e9"]).decode().splitlines() if ln.startswith("{")]
+    odo = ScanMatchingOdometry(Registration(pyname, **kw), dict(keyframe_delta_trans=1.0, keyframe_delta_angle=1.0, keyframe_delta_time=1e9))
+    assert len(lines) == len(clouds)
+    for k, (ln, c) in enumerate(zip(lines, clouds)):
+        kf_before = odo.n_keyframes
+        od = odo.matching(0.1 * k, c)
+        if k:
+            assert bool(ln["converged"]) == odo.registration.hasConverged(), k
+            assert np.array_equal(np.array(ln["T"], np.float32).reshape(4, 4).T, odo.registration.getFinalTransformation()), k
+        assert np.abs(np.array(ln["odom"], np.float64).reshape(4, 4).T - od).max() <= 2e-6, k
+        assert ln["n_keyframes"] == odo.n_keyframes and ln["keyframe_switch"] == int(k > 0 and odo.n_keyframes > kf_before)
+    if pyname == "FAST_GICP":            # the launch files' method for this sensor (16 sparse rings starve 1 m NDT voxels)
+        assert odo.n_keyframes >= 4      # at least three keyframe switches in the replayed stretch
+
+
+@pytest.mark.gpu
+def test_adapter_group_mode_matches_the_sequential_candidate_loop(driver, tmp_path):
+    """--devices: dgs_group_align_batch from C++ (one process, RCCL gather) == the per-candidate loop through pcl::Registration."""
+    tgt, src, _ = synth.planar_pair(n=8192)
+    clouds = [tgt, src, src[:5000].copy(), src[1000:7000].copy()]
+    p = str(tmp_path / "c.bin")
+    _write_clouds(p, clouds)
+    for devs, rccl in (("0", 1), ("0,0", 0)):
+        res = json.loads(subprocess.check_output([driver, "NDT_HIP", p, "--devices", devs]).decode().strip().splitlines()[-1])
+        g = res["group"]
+        assert g["create"] == 0 and g["status"] == 0 and g["size"] == len(devs.split(",")) and g["rccl"] == rccl
+        for a, b in zip(res["candidates"], g["candidates"]):
+            assert a["converged"] == b["converged"] and a["T"] == b["T"] and a["score"] == b["score"]
+        assert g["best"] == res["best"]

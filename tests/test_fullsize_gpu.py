@@ -96,7 +96,7 @@ def test_cfg3_vlp16_stream_gicp_odometry(oracle_lib):
     """FAST_GICP with the launch-file values (delta_graph_slam.launch:60-69), driven by the odometry mirror."""
     from delta_graph_slam_amd.odometry import ScanMatchingOdometry
     from tests.oracle_engine import OracleRegistration
-    clouds, poses = synth.vlp16_stream(n_frames=6)
+    clouds, poses = synth.vlp16_stream(n_frames=32)
     kw = dict(keyframe_delta_trans=1.0, keyframe_delta_angle=1.0, keyframe_delta_time=1e9)
     gpu = ScanMatchingOdometry(_reg("FAST_GICP", gicp_max_correspondence_distance=2.0, transformation_epsilon=0.1), kw)
     cpu = ScanMatchingOdometry(OracleRegistration("FAST_GICP", max_correspondence_distance=2.0, transformation_epsilon=0.1), kw)
@@ -109,7 +109,7 @@ def test_cfg3_vlp16_stream_gicp_odometry(oracle_lib):
             assert gpu.last_status.has_converged == cpu.last_status.has_converged
             assert abs(gpu.last_status.matching_error - cpu.last_status.matching_error) <= 1e-9 * cpu.last_status.matching_error
             assert abs(gpu.last_status.inlier_fraction - cpu.last_status.inlier_fraction) < 1e-9
-    assert gpu.n_keyframes == cpu.n_keyframes
+    assert gpu.n_keyframes == cpu.n_keyframes and gpu.n_keyframes >= 4      # >= 3 keyframe switches inside the 32 frames
 
 
 def test_cfg4_loop_batch_sharded_api_matches_sequential(oracle_lib):

@@ -45,6 +45,81 @@ def test_nn_index_is_exact_at_full_size_in_any_query_order(scans):
     # a single 65,536-query call (one cold round) returns the same thing as the 8-round call
     idx1, sq1 = r.nearestKSearch(qs[0])
     assert np.array_equal(idx1, idx[:65536]) and np.array_equal(sq1, sq[:65536])
+    # queries with non-finite coordinates have no neighbour (and must not send the walk past the end of the index)
+    bad = q[:1024].copy()
+    bad[5, 0] = np.nan
+    bad[9, 2] = np.inf
+    bi, bd = r.nearestKSearch(bad)
+    ok = np.isfinite(bad[:, :3]).all(1)
+    assert np.array_equal(bd[ok], sq[:1024][ok]) and not np.isfinite(bd[~ok]).any()
+    # the grid index of the fitness pass (DGS_NN_GRID=1: one lane per query, two grid levels, then the tree for what is still
+    # open) gives the very same float distances: aligned scans, far outliers, shuffled queries, non-finite queries
+    g = _grid_registration()
+    g.setInputTarget(tgt)
+    assert np.array_equal(g.nn_fitness_distances(q), sq)
+    d = g.nn_fitness_distances(bad)
+    assert np.array_equal(d[ok], sq[:1024][ok]) and not np.isfinite(d[~ok]).any()
+
+
+def _grid_registration(**kw):
+    """A handle with the grid passes of nn_grid.hip enabled (read from the environment at dgs_create)."""
+    import os
+    from delta_graph_slam_amd.registration import Registration
+    old = os.environ.get("DGS_NN_GRID")
+    os.environ["DGS_NN_GRID"] = "1"
+    try:
+        return Registration("NDT_OMP", **kw)
+    finally:
+        if old is None:
+            del os.environ["DGS_NN_GRID"]
+        else:
+            os.environ["DGS_NN_GRID"] = old
+
+
+@pytest.mark.parametrize("kind", ["indoor", "tiny", "line", "offset", "duplicates"])
+def test_fitness_index_is_exact_on_awkward_targets(kind):
+    """The grid's cell size is derived from the data on the device: check it on densities / extents far from the street scene."""
+    from scipy.spatial import cKDTree
+    from delta_graph_slam_amd.registration import Registration
+    rng = np.random.default_rng(7)
+    if kind == "indoor":
+        tgt, src, _ = synth.indoor_pair(n=60000)
+        q = src[:20000]
+    elif kind == "tiny":
+        tgt = np.ones((5, 4), np.float32)
+        tgt[:, :3] = rng.normal(size=(5, 3))
+        q = np.ones((300, 4), np.float32)
+        q[:, :3] = rng.normal(0, 3, (300, 3))
+    elif kind == "line":               # degenerate extent on two axes
+        tgt = np.ones((4000, 4), np.float32)
+        tgt[:, :3] = 0
+        tgt[:, 0] = rng.uniform(-50, 50, 4000)
+        q = np.ones((3000, 4), np.float32)
+        q[:, :3] = rng.normal(0, 1, (3000, 3))
+        q[:, 0] = rng.uniform(-60, 60, 3000)
+    elif kind == "offset":             # far from the origin: float cell coordinates lose bits
+        tgt = np.ones((30000, 4), np.float32)
+        tgt[:, :3] = rng.uniform(-5, 5, (30000, 3)) * [1, 1, 0.01] + [9000.0, -7000.0, 300.0]
+        q = np.ones((8000, 4), np.float32)
+        q[:, :3] = tgt[rng.integers(0, 30000, 8000), :3] + rng.normal(0, 0.05, (8000, 3)).astype(np.float32)
+    else:                              # all points in a handful of places: cells with thousands of points
+        base = rng.uniform(-2, 2, (7, 3))
+        tgt = np.ones((20000, 4), np.float32)
+        tgt[:, :3] = base[rng.integers(0, 7, 20000)]
+        q = np.ones((2000, 4), np.float32)
+        q[:, :3] = rng.uniform(-3, 3, (2000, 3))
+    r = _grid_registration()
+    r.setInputTarget(tgt)
+    d = r.nn_fitness_distances(q)
+    _, nn = cKDTree(tgt[:, :3].astype(np.float64)).query(q[:, :3].astype(np.float64), k=1)
+    want = f32_sqdist(q[:, :3], tgt[nn, :3])
+    idx, sq = r.nearestKSearch(q)
+    assert np.array_equal(d, sq)
+    # ... and the fitness score through the grid equals the one through the tree
+    t = Registration("NDT_OMP")
+    fa, fb = r.calc_fitness_score(tgt, q), t.calc_fitness_score(tgt, q)
+    assert abs(fa - fb) <= 1e-12 * fb      # same distances, another (fixed) summation order
+    assert np.all(d <= want) and np.all(d >= want * (1 - 1e-5))   # float ties may pick another point, never a farther one
 
 
 @pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("FAST_GICP", dict(gicp_max_correspondence_distance=2.0)),
