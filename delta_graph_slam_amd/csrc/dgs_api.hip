@@ -125,7 +125,9 @@ static int upload_cloud(dgs_handle* h, DevBuf<float4>& buf, const float* xyz16, 
   if (n == 0) return DGS_OK;
   DGS_HIP_TRY(h, buf.reserve((size_t)n));
   DGS_HIP_TRY(h, hipMemcpyAsync(buf.ptr, xyz16, (size_t)n * sizeof(float4), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-  if (!on_device) DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));  // the host pointer is not retained past return
+  // neither a host nor a device pointer is retained past return: the caller may free or overwrite its buffer at once (a device
+  // buffer handed in by a framework's caching allocator is recycled as soon as its tensor dies)
+  DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
   return DGS_OK;
 }
 
@@ -231,7 +233,7 @@ void dgs_destroy(dgs_handle* h) {
   h->gitems.release(); h->vvox.release(); h->vcell2vox.release();
   h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
-  h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
+  h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->vg_run_keys.release(); h->vg_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
   h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
   h->nn_partials.release(); h->scratch_cloud.release(); h->strict_rows.release(); h->strict_totals.release(); h->tgt_grid.release(); h->aux_grid.release();
   h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_out.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
@@ -318,10 +320,6 @@ int dgs_cloud_create(dgs_handle* h, const float* xyz16, int64_t n, int32_t on_de
   c->device = h->device;
   c->st.n = n;
   int rc = upload_cloud(h, c->st.pts, xyz16, n, on_device);
-  if (rc == DGS_OK && on_device) {  // the caller may free its buffer as soon as this returns
-    hipError_t e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { h->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; }
-  }
   if (rc != DGS_OK) {
     c->st.release();
     delete c;

@@ -130,6 +130,8 @@ struct dgs_handle {
   dgs::DevBuf<uint32_t> key_in, key_out, val_in, val_out, run_keys;
   dgs::DevBuf<int> run_counts, run_offsets;
   dgs::DevBuf<int> dev_scalars;      // [0]=num_runs, [1]=n_valid
+  dgs::DevBuf<uint32_t> vg_run_keys; // dgs_voxel_grid_filter's own runs / scalars: the NDT model's (above) stay what setInputTarget made them
+  dgs::DevBuf<int> vg_scalars;
   dgs::DevBuf<float> minmax_partial; // block partials + final 6 floats
   dgs::DevBuf<unsigned char> cub_temp;
   int64_t grid_cells = 0;

@@ -255,36 +255,35 @@ int voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, fl
   DGS_HIP_TRY(h, h->key_out.reserve(n));
   DGS_HIP_TRY(h, h->val_in.reserve(n));
   DGS_HIP_TRY(h, h->val_out.reserve(n));
-  DGS_HIP_TRY(h, h->run_keys.reserve(n));
+  DGS_HIP_TRY(h, h->vg_run_keys.reserve(n));
   DGS_HIP_TRY(h, h->run_counts.reserve(n));
   DGS_HIP_TRY(h, h->run_offsets.reserve(n));
-  DGS_HIP_TRY(h, h->dev_scalars.reserve(8));
+  DGS_HIP_TRY(h, h->vg_scalars.reserve(8));
   DGS_HIP_TRY(h, h->scratch_cloud.reserve(n));
   size_t t1 = 0, t2 = 0, t3 = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0, 32, st);
-  (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, h->key_out.ptr, h->run_keys.ptr, h->run_counts.ptr, h->dev_scalars.ptr, (int)n, st);
+  (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, h->key_out.ptr, h->vg_run_keys.ptr, h->run_counts.ptr, h->vg_scalars.ptr, (int)n, st);
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t3, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st);
   DGS_HIP_TRY(h, h->cub_temp.reserve(std::max(t1, std::max(t2, t3)) + 256));
-  DGS_HIP_TRY(h, hipMemsetAsync(h->dev_scalars.ptr, 0, 8 * sizeof(int), st));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->vg_scalars.ptr, 0, 8 * sizeof(int), st));
   DGS_HIP_TRY(h, hipMemsetAsync(h->run_counts.ptr, 0, (size_t)n * sizeof(int), st));
   const int nb = (int)((n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, in, n, g, h->key_in.ptr, h->val_in.ptr);
   size_t tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0, 32, st));
   tb = h->cub_temp.cap;
-  DGS_HIP_TRY(h, hipcub::DeviceRunLengthEncode::Encode(h->cub_temp.ptr, tb, h->key_out.ptr, h->run_keys.ptr, h->run_counts.ptr, h->dev_scalars.ptr, (int)n, st));
+  DGS_HIP_TRY(h, hipcub::DeviceRunLengthEncode::Encode(h->cub_temp.ptr, tb, h->key_out.ptr, h->vg_run_keys.ptr, h->run_counts.ptr, h->vg_scalars.ptr, (int)n, st));
   tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceScan::ExclusiveSum(h->cub_temp.ptr, tb, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st));
   hipLaunchKernelGGL(gather_kernel, dim3(nb), dim3(kBlock), 0, st, in, h->val_out.ptr, n, h->scratch_cloud.ptr);
-  hipLaunchKernelGGL(voxel_centroid_kernel, dim3(nb), dim3(kBlock), 0, st, h->scratch_cloud.ptr, h->run_keys.ptr, h->run_counts.ptr, h->run_offsets.ptr,
-                     h->dev_scalars.ptr, out, (int)std::min<int64_t>(out_capacity, INT32_MAX));
-  hipLaunchKernelGGL(voxel_count_kernel, dim3(1), dim3(1), 0, st, h->run_keys.ptr, h->dev_scalars.ptr);
+  hipLaunchKernelGGL(voxel_centroid_kernel, dim3(nb), dim3(kBlock), 0, st, h->scratch_cloud.ptr, h->vg_run_keys.ptr, h->run_counts.ptr, h->run_offsets.ptr,
+                     h->vg_scalars.ptr, out, (int)std::min<int64_t>(out_capacity, INT32_MAX));
+  hipLaunchKernelGGL(voxel_count_kernel, dim3(1), dim3(1), 0, st, h->vg_run_keys.ptr, h->vg_scalars.ptr);
   int* hs = reinterpret_cast<int*>(h->pinned);
-  DGS_HIP_TRY(h, hipMemcpyAsync(hs, h->dev_scalars.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipMemcpyAsync(hs, h->vg_scalars.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
   DGS_HIP_TRY(h, hipStreamSynchronize(st));
   DGS_HIP_TRY(h, hipGetLastError());
   *n_out = hs[2];
-  h->counts_stale = true;
   return DGS_OK;
 }
 

@@ -39,6 +39,9 @@ def _cloud_ptr(cloud):
             raise ValueError("cloud tensors must be float32 [N,4]")
         t = cloud.contiguous()
         if t.is_cuda:
+            # the handle works on a stream of its own: whatever produced this tensor on torch's current stream must have finished
+            # (include/dgs_reg.h, ordering contract for device pointers); the library is done with the buffer when its call returns
+            torch.cuda.current_stream(t.device).synchronize()
             return C.c_void_p(t.data_ptr()), t.shape[0], 1, t
         a = t.numpy()
         return a.ctypes.data_as(C.c_void_p), a.shape[0], 0, a
@@ -94,7 +97,11 @@ class Registration:
     def __init__(self, method: str = "NDT_OMP", device: int | None = None, **params):
         lib = L.load()
         self._lib = lib
-        m = L.METHOD_VGICP if "VGICP" in method else L.METHOD_GICP if "GICP" in method else L.METHOD_NDT
+        exact = {"NDT_OMP": L.METHOD_NDT, "NDT_HIP": L.METHOD_NDT, "FAST_GICP": L.METHOD_GICP, "FAST_GICP_HIP": L.METHOD_GICP,
+                 "FAST_VGICP": L.METHOD_VGICP, "FAST_VGICP_HIP": L.METHOD_VGICP}
+        if method not in exact:   # pcl::ICP / GICP / NDT, pclomp::GICP, FAST_VGICP_CUDA are other algorithms: not served here
+            raise NotImplementedError(f"registration_method {method!r} is not served by the HIP back-ends (served: {sorted(exact)})")
+        m = exact[method]
         p = L.Params()
         rc = lib.dgs_params_init(C.byref(p), m)
         if rc:
@@ -494,9 +501,11 @@ def select_registration_method(params: dict | None = None, device: int | None = 
     `params` plays the role of the private NodeHandle: keys are the reference's rosparam names
     (registration_method, reg_num_threads, reg_transformation_epsilon, reg_maximum_iterations,
     reg_max_correspondence_distance, reg_correspondence_randomness, reg_resolution, reg_nn_search_method).
-    "NDT_HIP" / "NDT_OMP" select NDT; "FAST_GICP_HIP" / "FAST_GICP" select GICP; "FAST_VGICP_HIP" / "FAST_VGICP" select the
-    voxelised GICP; unknown names warn and fall to NDT
-    exactly like registrations.cpp:88-91.
+    "NDT_HIP" / "NDT_OMP" select NDT (pclomp, registrations.cpp:101-120); "FAST_GICP_HIP" / "FAST_GICP" select GICP (:27-36);
+    "FAST_VGICP_HIP" / "FAST_VGICP" the voxelised GICP (:48-56).  The reference's other branches -- "ICP" (:59-64), "GICP" (:68-75),
+    "GICP_OMP" (:78-85), plain "NDT" (pcl::NDT, :96-100), "FAST_VGICP_CUDA" (:37-47) -- are different algorithms that stay with the
+    unpatched factory: here they raise NotImplementedError instead of silently running something else.  Names the reference
+    does not know either warn and fall to NDT_OMP exactly like registrations.cpp:88-91,121-123.
     """
     pr = dict(params or {})
     method = pr.get("registration_method", "NDT_OMP")
@@ -510,7 +519,9 @@ def select_registration_method(params: dict | None = None, device: int | None = 
     if method in ("FAST_VGICP", "FAST_VGICP_HIP"):      # registrations.cpp:48-56
         return Registration("FAST_VGICP", device=device, vgicp_resolution=float(pr.get("reg_resolution", 1.0)),
                             gicp_correspondence_randomness=int(pr.get("reg_correspondence_randomness", 20)), **common)
-    if "NDT" not in method:
+    if method in ("ICP", "GICP", "GICP_OMP", "NDT", "FAST_VGICP_CUDA"):
+        raise NotImplementedError(f"registration_method {method!r} is served by the reference's own factory branch, not by the HIP back-ends")
+    if method not in ("NDT_OMP", "NDT_HIP"):
         import sys
         print(f"warning: unknown registration type({method})\n       : use NDT", file=sys.stderr)
     nn = pr.get("reg_nn_search_method", "DIRECT7")

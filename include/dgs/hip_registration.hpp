@@ -15,8 +15,11 @@
 //     final_transformation_ = guess, which the callers already treat as "skip" (scan_matching_odometry_nodelet.cpp:222-226,
 //     loop_detector.hpp:149);
 //   * getFitnessScore(max_range) shadows pcl::Registration's (non-virtual there) and is answered on the device; call it
-//     through the derived type or use dgs_get_fitness_score -- through a base-class pointer PCL's own CPU loop runs on the
-//     same final_transformation_ and the base kd-tree (kept unless setKeepPclTree(false)).
+//     through the derived type (INTEGRATION.md section 3/4 patch the two call sites with a downcast) or use
+//     dgs_get_fitness_score -- through a base-class pointer PCL's own single-threaded CPU loop runs on the same
+//     final_transformation_ and the base kd-tree.  After setKeepPclTree(false) that tree is no longer rebuilt; it is then
+//     pointed at a one-point sentinel cloud at 1e30, so a base-pointer getFitnessScore() returns DBL_MAX ("no score")
+//     instead of a value computed against a stale target, and nearestKSearch reports an infinite distance.
 #pragma once
 
 #include <cfloat>
@@ -42,7 +45,8 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
 
   explicit HipRegistration(dgs_method method) {
     dgs_params_init(&params_, method);
-    this->reg_name_ = (method == DGS_METHOD_GICP) ? "dgs::HipRegistration<FAST_GICP>" : "dgs::HipRegistration<NDT>";
+    this->reg_name_ = (method == DGS_METHOD_GICP) ? "dgs::HipRegistration<FAST_GICP>" : (method == DGS_METHOD_VGICP) ? "dgs::HipRegistration<FAST_VGICP>"
+                                                                                        : "dgs::HipRegistration<NDT>";
     // the reference's setters below write into params_; PCL's own setters (epsilon, iterations, distance) are read at align()
     this->transformation_epsilon_ = params_.transformation_epsilon;
     this->max_iterations_ = params_.maximum_iterations;
@@ -61,17 +65,25 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
   void setNeighborhoodSearchMethod(int method) { params_.ndt_search_method = method; dirty_ = true; }  // dgs_ndt_search == pclomp order
   void setCorrespondenceRandomness(int k) { params_.gicp_correspondence_randomness = k; dirty_ = true; }
   void setStepSize(double s) { params_.ndt_step_size = s; dirty_ = true; }
+  // dgs_ndt_strict_order: 0 fast (default), 1 upstream operation order, 2 + index-order sums (validation modes, dgs_reg.h)
+  void setNdtStrictOrder(int order) { params_.ndt_strict_order = order; dirty_ = true; }
   void setOulierRatio(double r) { params_.ndt_outlier_ratio = r; dirty_ = true; }  // (sic) upstream spelling
   void setRotationEpsilon(double e) { params_.gicp_rotation_epsilon = e; dirty_ = true; }
   void setRegularizationMethod(int m) { params_.gicp_regularization = m; dirty_ = true; }
   void setDevice(int ordinal) { params_.device = ordinal; dirty_ = true; }
   // false: skip PCL's CPU kd-tree rebuild in initCompute() on every new target (then use getInlierFraction() instead of
   // getSearchMethodTarget()->nearestKSearch())
-  void setKeepPclTree(bool keep) { keep_pcl_tree_ = keep; this->force_no_recompute_ = !keep; }
+  void setKeepPclTree(bool keep) {
+    keep_pcl_tree_ = keep;
+    this->force_no_recompute_ = !keep;
+    if (!keep) park_pcl_tree();
+    else this->target_cloud_updated_ = true;   // PCL rebuilds its tree at the next align()
+  }
 
   void setInputTarget(const PointCloudTargetConstPtr& cloud) override {
     Base::setInputTarget(cloud);
     target_dirty_ = true;
+    if (!keep_pcl_tree_) park_pcl_tree();
   }
   void setInputSource(const PointCloudSourceConstPtr& cloud) override {
     Base::setInputSource(cloud);
@@ -133,6 +145,19 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
     this->nr_iterations_ = last_.iterations;
   }
 
+  // the base kd-tree is not maintained (setKeepPclTree(false)): make that visible instead of leaving the previous target in it
+  void park_pcl_tree() {
+    if (!sentinel_) {
+      typename pcl::PointCloud<PointTarget>::Ptr c(new pcl::PointCloud<PointTarget>());
+      c->points.resize(1);
+      c->points[0].x = c->points[0].y = c->points[0].z = 1e30f;
+      c->width = 1;
+      sentinel_ = c;
+    }
+    if (this->tree_) this->tree_->setInputCloud(sentinel_);
+  }
+
+  typename pcl::PointCloud<PointTarget>::ConstPtr sentinel_;
   dgs_params params_{};
   dgs_params applied_{};
   dgs_handle* handle_ = nullptr;

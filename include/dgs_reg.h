@@ -13,8 +13,11 @@
  *   - Clouds are pcl::PointXYZ arrays: float[n][4] = x, y, z, pad (16-byte stride; the pad value is ignored).
  *   - Transforms are Eigen::Matrix4f memory: 16 floats, COLUMN-major.
  *   - `on_device` != 0 means the pointer is a device (HBM) pointer valid on the handle's device; the call then
- *     enqueues on the handle's stream and does not touch host memory.  With host pointers the library copies
- *     at the call and never retains the pointer.
+ *     works on the handle's stream and does not touch host memory.  Ordering contract for device pointers: the DATA must be
+ *     complete when the call is made (the handle's stream is not ordered against the stream that produced it: synchronise that
+ *     stream, or make the handle share it with dgs_set_stream), and the library has finished READING the buffer when the call
+ *     returns (set_input_* copy it, align_batch / fitness calls read it in place), so it may be freed or reused at once.
+ *     With host pointers the library copies at the call and never retains the pointer.
  *   - A handle is used by one thread at a time; different handles are independent (two live handles per
  *     process is the reference's normal case: odometry + loop detector).
  *   - There is NO CPU fallback: every call fails with DGS_ERR_HIP when no gfx950 device is usable.

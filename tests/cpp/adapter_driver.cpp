@@ -91,6 +91,16 @@ int main(int argc, char** argv) {
     best = (int)c;
   }
   jprintf("], \"best\": %d", best);
+  {
+    // setKeepPclTree(false): the base kd-tree is parked on a sentinel, so the base-pointer score is "none" (DBL_MAX), never stale
+    auto* hip = dynamic_cast<dgs::HipRegistration<PointT, PointT>*>(registration.get());
+    hip->setKeepPclTree(false);
+    registration->setInputTarget(clouds[0]);
+    registration->setInputSource(clouds[1]);
+    registration->align(*aligned, Eigen::Matrix4f::Identity());
+    jprintf(", \"parked_base_score_is_max\": %d, \"parked_device_score\": %.17g", registration->getFitnessScore(DBL_MAX) == DBL_MAX ? 1 : 0,
+            hip->getFitnessScore(DBL_MAX));
+  }
   // ---- the same candidate loop, sharded over several devices of this process (what the nodelet links for loop closure)
   std::vector<int32_t> devices;
   for (int a = 3; a + 1 < argc; a++)

@@ -1,6 +1,8 @@
 """CPU tests of the host-side mirror: 2-D/3-D guess flattening, candidate filtering, arg-min tie-breaking, generators."""
 import hashlib
 
+import pytest
+
 import numpy as np
 
 from delta_graph_slam_amd import synth
@@ -161,3 +163,13 @@ def test_record_path_equals_dict_path():
     assert np.array_equal(ra, rb) and np.array_equal(a.guesses, b.guesses)
     assert list(ra[:, 0]) == list(range(n))
     assert LoopDetector.select_best(ra)[0] == LoopDetector.select_best(rb)[0]
+
+
+def test_factory_refuses_the_reference_branches_it_does_not_serve():
+    """registrations.cpp:59-100: ICP / GICP / GICP_OMP / plain NDT / FAST_VGICP_CUDA are other algorithms -- never silently replaced."""
+    from delta_graph_slam_amd.registration import Registration, select_registration_method
+    for name in ("ICP", "GICP", "GICP_OMP", "NDT", "FAST_VGICP_CUDA"):
+        with pytest.raises(NotImplementedError):
+            select_registration_method({"registration_method": name})
+        with pytest.raises(NotImplementedError):
+            Registration(name)

@@ -203,3 +203,40 @@ def test_voxel_grid_filter_matches_oracle(reg_cls, oracle_lib, leaf):
     dout = r.voxel_grid_filter(torch.from_numpy(cloud).cuda(), leaf)     # device in -> device out
     assert dout.is_cuda and np.array_equal(dout.cpu().numpy(), ref)
     assert r.voxel_grid_filter(np.zeros((0, 4), np.float32), leaf).shape == (0, 4)
+
+
+def test_voxel_grid_filter_leaves_the_ndt_model_bookkeeping_alone(reg_cls):
+    """The odometry flow down-samples on the same registration object between setInputTarget and align
+    (scan_matching_odometry_nodelet.cpp:184): counts / voxel dump must still describe the NDT target afterwards."""
+    tgt, src, _ = synth.planar_pair(n=16384)
+    r = reg_cls("NDT_OMP", ndt_resolution=1.0)
+    r.setInputTarget(tgt)
+    before, vox_before = r.counts(), r.ndt_voxels()
+    small = r.voxel_grid_filter(src, 0.5)
+    assert 0 < small.shape[0] < src.shape[0]
+    after, vox_after = r.counts(), r.ndt_voxels()
+    assert before == after
+    assert np.array_equal(vox_before["keys"], vox_after["keys"]) and np.array_equal(vox_before["mean"], vox_after["mean"])
+    r2 = reg_cls("NDT_OMP", ndt_resolution=1.0)      # also when the counts were never read before the filter ran
+    r2.setInputTarget(tgt)
+    r2.voxel_grid_filter(src, 0.5)
+    assert r2.counts() == before
+
+
+def test_device_tensors_may_die_right_after_the_call(reg_cls, oracle_lib):
+    """include/dgs_reg.h ordering contract: the library has finished reading a device buffer when set_input_* returns, so a
+    temporary tensor may be recycled by the caching allocator immediately (the pattern of __graft_entry__.smoke())."""
+    import torch
+    tgt, src, _ = synth.planar_pair(n=16384)
+    r = reg_cls("NDT_OMP", ndt_resolution=1.0)
+    r.setInputTarget(torch.from_numpy(tgt).cuda())
+    junk = [torch.full((16384, 4), float(k), device="cuda") for k in range(8)]      # re-uses the freed blocks at once
+    r.setInputSource(torch.from_numpy(src).cuda())
+    junk += [torch.full((16384, 4), -1.0, device="cuda") for _ in range(8)]
+    torch.cuda.synchronize()
+    r.align()
+    h = reg_cls("NDT_OMP", ndt_resolution=1.0)
+    h.setInputTarget(tgt)
+    h.setInputSource(src)
+    h.align()
+    assert np.array_equal(r.getFinalTransformation(), h.getFinalTransformation()) and len(junk) == 16
