@@ -206,7 +206,8 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   }
   h->device = dev;
   h->own_stream = true;
-  if (const char* e = std::getenv("DGS_NN_GRID")) h->use_grid = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
+  if (const char* e = std::getenv("DGS_NN_GRID_FACTOR")) h->grid_spacing_factor = std::max(0.5f, (float)std::atof(e));
   std::memset(h->final_T, 0, sizeof(h->final_T));
   h->final_T[0] = h->final_T[5] = h->final_T[10] = h->final_T[15] = 1.f;
   *out = h;
@@ -479,8 +480,9 @@ int dgs_nn_fitness_distances(dgs_handle* h, const float* queries, int64_t m, int
   h->err.clear();
   if (set_device(h)) return DGS_ERR_HIP;
   if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
-  if (!h->use_grid) return DGS_ERR_UNSUPPORTED;
+  if (h->grid_mode == 0) return DGS_ERR_UNSUPPORTED;
   if (m == 0) return DGS_OK;
+  h->use_grid = true;
   if (side_join(h) != DGS_OK) return DGS_ERR_HIP;
   int rc = ensure_target_index(h);
   if (rc) return rc;
@@ -579,6 +581,7 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
   }
   // the fitness pass needs the target's NN index only after the last iteration: build it on the side stream meanwhile
   // (a dozen tiny launches, 0.15 ms on the critical path otherwise); kernels timed one by one stay on one stream
+  h->use_grid = grid_wanted(h, total);
   if (compute_fitness && (!h->tgt->bvh.valid || (h->use_grid && !h->tgt_grid.valid)) && !h->prof.enabled) {
     int rs = side_fork(h);
     if (rs == DGS_OK) rs = ensure_target_index(h, h->side_stream);
@@ -705,7 +708,8 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const
   int rc = upload_cloud(h, h->aux_cloud1, cloud1, n1, on_device);
   if (rc == DGS_OK) rc = upload_cloud(h, h->aux_cloud2, cloud2, n2, on_device);
   if (rc == DGS_OK) rc = bvh_build(h, h->aux_bvh, h->aux_cloud1.ptr, n1);
-  if (rc == DGS_OK && h->use_grid) rc = nn_grid_build(h, h->aux_grid, h->aux_bvh, h->aux_cloud1.ptr, n1);
+  const bool aux_grid = grid_wanted(h, n2);
+  if (rc == DGS_OK && aux_grid) rc = nn_grid_build(h, h->aux_grid, h->aux_bvh, h->aux_cloud1.ptr, n1);
   if (rc != DGS_OK) return rc;
   // stage pointer / size / transform exactly like the single-pair fitness path, but against the auxiliary index
   hipStream_t st = h->stream;
@@ -724,7 +728,7 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const
   DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, base + 64, sizeof(float) * 16, hipMemcpyHostToDevice, st));
   double sum = 0;
   int64_t cnt = 0, inl = 0;
-  rc = nn_fitness_batch_on(h, h->aux_bvh, (h->use_grid && h->aux_grid.valid) ? &h->aux_grid : nullptr, 1, h->src_ptrs.ptr, h->src_sizes.ptr, ni, reinterpret_cast<const float*>(h->inits.ptr), 64, max_range, 0.0,
+  rc = nn_fitness_batch_on(h, h->aux_bvh, (aux_grid && h->aux_grid.valid) ? &h->aux_grid : nullptr, 1, h->src_ptrs.ptr, h->src_sizes.ptr, ni, reinterpret_cast<const float*>(h->inits.ptr), 64, max_range, 0.0,
                            &sum, &cnt, &inl);
   if (rc != DGS_OK) return rc;
   *score = cnt > 0 ? sum / (double)cnt : DBL_MAX;

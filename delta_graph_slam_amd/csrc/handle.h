@@ -162,7 +162,12 @@ struct dgs_handle {
   dgs::DevBuf<double> nn_partials;
   dgs::DevBuf<float4> scratch_cloud;
   dgs::NnGrid tgt_grid, aux_grid;   // fitness-pass index over the current target / over cloud1 of dgs_calc_fitness_score
-  bool use_grid = false;            // DGS_NN_GRID=1 in the environment at dgs_create: grid passes in front of the tree walk (A/B measurements)
+  int grid_mode = 0;                // DGS_NN_GRID at dgs_create: 0 (default) tree walk only, >= 1 grid pass in front of it, -1 grid pass for big batches.
+                                    // Measured on the 32 x 65,536 bench step: the grid pass cuts the fitness kernels from 0.83 to 0.69 ms, but
+                                    // its build and queue traffic give the gain back (2.99 vs 3.00 ms per step), so it stays opt-in.
+  bool use_grid = false;            // decision for the current target (grid_wanted)
+  int grid_levels = 1;              // DGS_NN_GRID=2: also the coarse-block pass between the fine-block pass and the tree
+  float grid_spacing_factor = 6.f;  // DGS_NN_GRID_FACTOR: fine cell = factor x 2^floor(log2(median spacing))
 
   // ---- calc_fitness_score between two arbitrary clouds (InformationMatrixCalculator): own buffers, the registration's
   // target / source / result are left untouched
@@ -218,7 +223,9 @@ int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs
 int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
                         const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
-int ensure_target_index(dgs_handle* h, hipStream_t st = nullptr);   // tree + grid over the current target (no-op when both are valid)
+int ensure_target_index(dgs_handle* h, hipStream_t st = nullptr);   // tree (+ grid when h->use_grid) over the current target
+// the grid pass pays for its build (one more sort of the target) from ~4 x 65,536 queries on: fitness of a candidate batch
+inline bool grid_wanted(const dgs_handle* h, int64_t queries) { return h->grid_mode > 0 || (h->grid_mode < 0 && queries >= 262144); }
 // nn_grid.hip
 int nn_grid_build(dgs_handle* h, NnGrid& G, const Bvh& bvh, const float4* pts, int64_t n, hipStream_t st = nullptr);
 int nn_grid_launch_fitness(dgs_handle* h, NnGrid& G, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_n, const float* d_T,

@@ -13,10 +13,10 @@
 //     is its end).  No table has an entry per fine cell, so the boxes are implicit (computed from the indices) and c can be small;
 //   * c is chosen ON THE DEVICE from the data: ~4 x the median distance between consecutive points of the Hilbert order (a
 //     robust local spacing: dense regions dominate the median), enlarged until the L2 table fits its budget.
-// Query: the own fine cell, then the rest of the 3 x 3 x 3 fine block; proven exact when best <= (distance to the block's
-// border)^2.  Open queries search the 3 x 3 x 3 coarse block, then the 3 x 3 x 3 L2 block, through the masks (empty space costs
-// nothing, every candidate cell is pruned by its implicit box against the best distance so far); whatever is still open --
-// queries many metres from every target point -- falls back to the 8-lane tree walk bounded by the best distance found.
+// Query, pass 1 (one lane per query): the 3 x 3 x 3 fine block; proven exact when best <= (distance to the block's border)^2
+// (~80 % of the queries of aligned scans).  Open queries are queued (compaction: later passes run on full waves) and go to the
+// 8-lane tree walk of nn_bvh.hip bounded by the best distance found; an optional middle pass (DGS_NN_GRID=2) searches the
+// 3 x 3 x 3 coarse block through the masks first.  Distances land in a per-query array and are summed in a fixed order.
 // Squared distances are FLANN's float sequence (sqdist_rn); box bounds are shrunk by 0.2 % against rounding: pruning only, the
 // minimum over the target is exact.
 #include <hipcub/hipcub.hpp>
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void grid_spacing_kernel(const float4* __re
   if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
 
-__global__ void grid_params_kernel(const float* __restrict__ mm6, const unsigned* __restrict__ hist, int n, NnGridParams* __restrict__ out) {
+__global__ void grid_params_kernel(const float* __restrict__ mm6, const unsigned* __restrict__ hist, int n, float spacing_factor, NnGridParams* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   NnGridParams g;
   float lo[3] = {mm6[0], mm6[1], mm6[2]}, hi[3] = {mm6[3], mm6[4], mm6[5]};
@@ -64,7 +64,7 @@ __global__ void grid_params_kernel(const float* __restrict__ mm6, const unsigned
     if (total && 2 * acc >= total) med = e;
   }
   const float ext = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), fmaxf(hi[2] - lo[2], 1e-3f));
-  float c = (med >= 0) ? 6.0f * __uint_as_float((unsigned)med << 23) : ext / 64.f;   // 2^e <= d < 2^(e+1): ~4 x the median itself
+  float c = (med >= 0) ? spacing_factor * __uint_as_float((unsigned)med << 23) : ext / 64.f;   // 2^e <= median < 2^(e+1)
   c = fmaxf(c, ext / 4096.f);
   for (int it = 0; it < 96; it++) {
     long long cells = 1;
@@ -174,7 +174,7 @@ int nn_grid_build(dgs_handle* h, NnGrid& G, const Bvh& bvh, const float4* pts, i
   DGS_HIP_TRY(h, hipMemsetAsync(G.hist.ptr, 0, 256 * sizeof(unsigned), st));
   DGS_HIP_TRY(h, hipMemsetAsync(G.run_counts.ptr, 0, (size_t)(n + 2) * sizeof(int), st));   // the scan runs over n + 1 entries: cstart[runs] = n
   hipLaunchKernelGGL(grid_spacing_kernel, dim3(std::min(nb, 256)), dim3(kBlock), 0, st, bvh.sorted.ptr, n, G.hist.ptr);
-  hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(1), 0, st, d_mm, G.hist.ptr, n, G.params.ptr);
+  hipLaunchKernelGGL(grid_params_kernel, dim3(1), dim3(1), 0, st, d_mm, G.hist.ptr, n, h->grid_spacing_factor, G.params.ptr);
   hipLaunchKernelGGL(grid_key_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, G.params.ptr, G.keys.ptr, G.vals.ptr);
   size_t tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, G.keys.ptr, G.keys_alt.ptr, G.vals.ptr, G.vals_alt.ptr, n, 0, kGridKeyBits, st));
@@ -312,28 +312,60 @@ __device__ __forceinline__ void grid_setup(GridQuery& q, const NnGridParams& g, 
   }
 }
 
-__device__ __forceinline__ bool grid_level0(const NnGridView& v, const NnGridParams& g, GridQuery& q, const int* f, const int* K) {
-  {
-    const NnCoarse E = grid_coarse(v, g, K[0], K[1], K[2]);
-    const int bit = (f[0] & 3) | ((f[1] & 3) << 2) | ((f[2] & 3) << 4);
-    if ((E.mask >> bit) & 1ull) {
-      const int idx = E.base + __popcll(E.mask & ((1ull << bit) - 1ull));
-      grid_scan(v.sorted, v.cstart[idx], v.cstart[idx + 1], q);
+// Level 0, ONE LANE PER QUERY.  Phase A lists, per lane, the point ranges of the 3 x 3 x 3 fine block: per (y, z) row the
+// x-neighbours inside one coarse cell are consecutive bits of its mask, hence ONE contiguous range of the sorted points; a row
+// touches at most two coarse cells.  Phase B scans the concatenated ranges in ONE loop, so that a wave's trip count is the largest
+// per-lane point total and not the sum of the largest cell of every step (nested per-cell loops cost 6 k instructions per wave).
+// Measured alternatives: nested per-cell loops with box pruning (0.33 ms for this pass alone), larger cells (the
+// scan is bound by the L1 addresser: 64 scattered 16-byte loads per instruction), and an 8-lanes-per-query cooperative search
+// through the masks with nearest-first proposals (coalesced scans, but 2-4 x slower overall: the per-round control is heavy).
+constexpr int kGridSegs = 18;   // 9 rows x <= 2 coarse cells
+__device__ __forceinline__ bool grid_level0(const NnGridView& v, const NnGridParams& g, GridQuery& q, const int* f, const int* K, int2* __restrict__ segs) {
+  int nseg = 0;
+  const int Kx0 = (f[0] - 1) >> 2, Kx1 = (f[0] + 1) >> 2;
+#pragma unroll
+  for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+      const int y = f[1] + dy, z = f[2] + dz;
+      const int rowshift = ((y & 3) << 2) | ((z & 3) << 4);
+#pragma unroll
+      for (int sgm = 0; sgm < 2; sgm++) {
+        const int Kx = sgm ? Kx1 : Kx0;
+        if (sgm && Kx1 == Kx0) continue;
+        const NnCoarse E = grid_coarse(v, g, Kx, y >> 2, z >> 2);
+        const int xlo = max(f[0] - 1 - 4 * Kx, 0), xhi = min(f[0] + 1 - 4 * Kx, 3);
+        const unsigned sel = (unsigned)(E.mask >> rowshift) & (((2u << xhi) - 1u) ^ ((1u << xlo) - 1u)) & 0xFu;
+        if (sel) {
+          const int first = __ffs((int)sel) - 1;
+          const int idx = E.base + __popcll(E.mask & ((1ull << (rowshift + first)) - 1ull));
+          segs[nseg * kBlock] = make_int2(v.cstart[idx], v.cstart[idx + __popc(sel)]);
+          nseg++;
+        }
+      }
+    }
+  // phase B
+  float best = q.best;
+  int e = 0;
+  int2 cur = nseg ? segs[0] : make_int2(0, 0);
+  GRID_STAT(for (int t = 0; t < nseg; t++) { q.st_pts += segs[t * kBlock].y - segs[t * kBlock].x; q.st_cells += 1; })
+  while (e < nseg) {
+    float4 p[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) p[t] = load16_at(v.sorted, (unsigned)min(cur.x + t, cur.y - 1));   // the tail repeats the last point
+#pragma unroll
+    for (int t = 0; t < 4; t++) best = fminf(best, sqdist_rn(q.x, q.y, q.z, p[t].x, p[t].y, p[t].z));
+    cur.x += 4;
+    if (cur.x >= cur.y) {
+      e++;
+      if (e < nseg) cur = segs[e * kBlock];
     }
   }
-  for (int Kz = (f[2] - 1) >> 2; Kz <= (f[2] + 1) >> 2; Kz++)
-    for (int Ky = (f[1] - 1) >> 2; Ky <= (f[1] + 1) >> 2; Ky++)
-      for (int Kx = (f[0] - 1) >> 2; Kx <= (f[0] + 1) >> 2; Kx++) {
-        const NnCoarse E = grid_coarse(v, g, Kx, Ky, Kz);
-        unsigned long long m = E.mask & grid_box_mask(max(f[0] - 1 - 4 * Kx, 0), min(f[0] + 1 - 4 * Kx, 3), max(f[1] - 1 - 4 * Ky, 0), min(f[1] + 1 - 4 * Ky, 3),
-                                                      max(f[2] - 1 - 4 * Kz, 0), min(f[2] + 1 - 4 * Kz, 3));
-        if (Kx == K[0] && Ky == K[1] && Kz == K[2]) m &= ~(1ull << ((f[0] & 3) | ((f[1] & 3) << 2) | ((f[2] & 3) << 4)));   // the own cell is done
-        grid_visit_fine(v, E, m, Kx, Ky, Kz, q);
-      }
+  grid_take(q, best);
   return q.best <= grid_proven_sq(q, f, 1.f, g.c);
 }
 
-// ---- level 1: the rest of the 3 x 3 x 3 coarse block
+// ---- level 1 (optional pass, DGS_NN_GRID=2): the rest of the 3 x 3 x 3 coarse block, one lane per query, nested loops
 __device__ __forceinline__ bool grid_level1(const NnGridView& v, const NnGridParams& g, GridQuery& q, const int* f, const int* K) {
   for (int dz = -1; dz <= 1; dz++)
     for (int dy = -1; dy <= 1; dy++)
@@ -399,6 +431,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_level0_kernel(const NnGridView
   const bool alive = i < n;
   bool open = false;
   float best = INFINITY;
+  __shared__ int2 segs[kGridSegs * kBlock];   // [segment][thread]: 36 KB per workgroup
   if (alive) {
     float x, y, z;
     batch_point(B, pair, i, x, y, z);
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_level0_kernel(const NnGridView
     int f[3], K[3];
     grid_setup(q, g, x, y, z, INFINITY, f, K);
     // a query with a NaN coordinate has no neighbour (its box tests would all read 0): answered +inf here, never queued
-    open = (x == x && y == y && z == z) && !grid_level0(v, g, q, f, K);
+    open = (x == x && y == y && z == z) && !grid_level0(v, g, q, f, K, segs + threadIdx.x);
     best = q.best;
     GRID_STAT(best = (float)(0 + 4 * min(q.st_cells, 63) + 256 * min(q.st_pts, 65535));)
     if (!open) dist[(size_t)pair * B.max_n + i] = best;
@@ -415,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_level0_kernel(const NnGridView
   queue_push(Q, open, (unsigned)(pair * B.max_n + i), best);
 }
 
-// pass 2: the queued queries, one lane each, level 1 (3 x 3 x 3 coarse cells through the occupancy masks)
+// pass 2 (optional, DGS_NN_GRID=2): the queued queries, one lane each, level 1 (3 x 3 x 3 coarse cells through the occupancy masks)
 __global__ __launch_bounds__(kBlock) void nn_grid_level1_kernel(const NnGridView v, const NnBatch B, float* __restrict__ dist, const NnQueue Qin, const NnQueue Qout) {
   const int count = *Qin.count;
   const NnGridParams g = *v.params;
@@ -520,9 +553,10 @@ int nn_grid_distances(dgs_handle* h, NnGrid& G, const Bvh& index, int n_pairs, c
   const unsigned bx = (unsigned)((max_n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(nn_grid_level0_kernel, dim3(bx, n_pairs), dim3(kBlock), 0, st, v, B, G.dist.ptr, Q1);
   // the queues' lengths stay on the device: the next passes run grid-stride loops over them (a workgroup without work leaves at once)
-  hipLaunchKernelGGL(nn_grid_level1_kernel, dim3((unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0, st, v, B, G.dist.ptr, Q1, Q2);
+  if (h->grid_levels >= 2)
+    hipLaunchKernelGGL(nn_grid_level1_kernel, dim3((unsigned)std::min<size_t>((total + kBlock - 1) / kBlock, 2048)), dim3(kBlock), 0, st, v, B, G.dist.ptr, Q1, Q2);
   hipLaunchKernelGGL(nn_tree_queue_kernel, dim3((unsigned)std::min<size_t>((total + kBlock / 8 - 1) / (kBlock / 8), 2048)), dim3(kBlock), 0, st,
-                     make_bvh_view(index), B, G.dist.ptr, Q2);
+                     make_bvh_view(index), B, G.dist.ptr, h->grid_levels >= 2 ? Q2 : Q1);
   DGS_HIP_TRY(h, hipGetLastError());
   return DGS_OK;
 }

@@ -98,6 +98,30 @@ def gicp_pair(name, method, tgt, src, guess, reps, cpu, orc, threads, **kw):
     t_warm, _ = timed(lambda: reg.align(guess), reps)
     out = {"config": name, "points": int(src.shape[0]), "gpu_first_align_ms": 1e3 * t_cold, "gpu_repeat_align_ms": 1e3 * t_warm,
            "iterations": reg.last_result.iterations, "evaluations": reg.last_result.evaluations, "converged": bool(reg.hasConverged())}
+    # ---- roofline objects (SURVEY.md 8d byte formulas; HIP-event kernel times on the handle's stream)
+    from delta_graph_slam_amd import _lib as L
+    Ns, Nt = int(src.shape[0]), int(tgt.shape[0])
+    reg.profile_enable(True)
+    reg.profile_reset()
+    cold()
+    ms_cov, n_cov = reg.profile_get(L.K_GICP_COVARIANCE)
+    reg.profile_reset()
+    for _ in range(reps):
+        reg.align(guess)
+    ms_lin, n_lin = reg.profile_get(L.K_GICP_LINEARIZE)
+    ms_nn, n_nn = reg.profile_get(L.K_NN_SEARCH)
+    reg.profile_enable(False)
+    cov_bytes = (Ns + Nt) * (16 + 24)                                      # read the points, write a symmetric 3x3 per point
+    lin_bytes = Ns * 40 + Ns * 40 + 16 * Nt + 344                          # per linearisation, Nc taken as Ns (upper bound)
+    out["roofline"] = {
+        "covariance": {"bound": "hbm", "kernel": "gicp_covariance_kernel (both clouds)", "algorithmic_bytes": cov_bytes, "kernel_ms": ms_cov,
+                       "launches": n_cov, "achieved": cov_bytes / (ms_cov * 1e-3) / 1e9 if ms_cov > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                       "frac": cov_bytes / (ms_cov * 1e-3) / 1e9 / 8000.0 if ms_cov > 0 else None},
+        "linearize": {"bound": "hbm", "kernel": ("vgicp_linearize_kernel" if method == "FAST_VGICP" else "gicp_correspond_kernel + gicp_linearize_kernel"),
+                      "algorithmic_bytes_per_evaluation": lin_bytes, "launches": n_lin, "avg_launch_us": 1e3 * (ms_lin + ms_nn) / max(n_lin, 1),
+                      "achieved": lin_bytes * n_lin / ((ms_lin + ms_nn) * 1e-3) / 1e9 if ms_lin + ms_nn > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                      "frac": lin_bytes * n_lin / ((ms_lin + ms_nn) * 1e-3) / 1e9 / 8000.0 if ms_lin + ms_nn > 0 else None,
+                      "correspond_ms_total": ms_nn, "linearize_ms_total": ms_lin}}
     if cpu:
         if method == "FAST_VGICP":
             o = orc.VgicpOracle(resolution=kw.get("vgicp_resolution", 1.0), num_threads=threads)

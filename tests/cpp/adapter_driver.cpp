@@ -98,8 +98,7 @@ int main(int argc, char** argv) {
     registration->setInputTarget(clouds[0]);
     registration->setInputSource(clouds[1]);
     registration->align(*aligned, Eigen::Matrix4f::Identity());
-    jprintf(", \"parked_base_score_is_max\": %d, \"parked_device_score\": %.17g", registration->getFitnessScore(DBL_MAX) == DBL_MAX ? 1 : 0,
-            hip->getFitnessScore(DBL_MAX));
+    jprintf(", \"parked_base_score\": %.17g, \"parked_device_score\": %.17g", registration->getFitnessScore(DBL_MAX), hip->getFitnessScore(DBL_MAX));
   }
   // ---- the same candidate loop, sharded over several devices of this process (what the nodelet links for loop closure)
   std::vector<int32_t> devices;
