@@ -79,6 +79,9 @@ struct NdtPair {
   float hang[15][3];   // eq. 6.21 tables
   int need_hessian;
   int active;          // 0: every kernel returns immediately for this pair
+  int last_launch;     // fused launches: index of the last launch this pair takes part in (INT_MAX while it iterates).  Written by
+                       // the pair's closing workgroup DURING a launch without changing what workgroups of that launch read
+  int ticket;          // fused launches: slices of this pair that have finished the current launch
   NdtSolver s;
   float final_T[16];   // column-major, = final_transformation_
   double traj[kTrajCap][6];

@@ -150,6 +150,7 @@ struct dgs_handle {
   dgs::DevBuf<int> src_sizes;
   dgs::NdtConsts consts{};
   int64_t last_evaluations = 0;
+  bool ndt_fused = true;              // DGS_NDT_FUSED=0 at dgs_create: (derivatives, solve) launch pairs instead of fused launches
 
   // pinned host staging
   void* pinned = nullptr;

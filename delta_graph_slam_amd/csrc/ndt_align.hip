@@ -20,6 +20,7 @@
 //     immediate returns.  The host only polls a "pairs done" counter once per chunk of iterations.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "handle.h"
@@ -63,11 +64,25 @@ __device__ __forceinline__ void neighbour_offset(int k, int& dx, int& dy, int& d
   }
 }
 
-template <int SEARCH>
-__global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
-                                                                 const NdtPair* __restrict__ pairs, const VoxelGrid g, const double gd1,
-                                                                 const float gd2, const int leaf_pow2, double* __restrict__ partials,
-                                                                 const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks) {
+__device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch);
+
+// FUSED = false: derivatives only; ndt_solve_kernel (one workgroup per pair) follows as a second launch.
+// FUSED = true: the workgroup of a pair that finishes LAST (a per-pair ticket) also sums the pair's partial rows in their fixed
+// order and advances the optimiser, so an evaluation is ONE launch: no second kernel boundary, no second launch latency, and the
+// optimiser steps of pairs that finish early overlap the derivative work of the others.  The hand-off is the write-through form
+// of the agent-scope recipe: every byte of a row is stored sc1 (8-byte agent-scope stores), the storing wave drains, a
+// workgroup barrier, ONE lane takes the ticket with an agent-scope atomic add; the workgroup whose add came last reads the rows
+// with sc1 loads behind a barrier that lane joins.  Results do not depend on placement or timing; the rows are still added in
+// slice order.  `launch` numbers the launches of one align: a pair takes part while launch <= its last_launch word,
+// which its closing workgroup may write during a launch without changing what the other workgroups of that launch see.
+// __launch_bounds__(kBlock, 4) holds the kernel at the derivative loop's 4 waves per SIMD; the optimiser tail (one workgroup per
+// pair and launch) spills what does not fit.
+template <int SEARCH, bool FUSED>
+__global__ __launch_bounds__(kBlock, 4) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
+                                                                    NdtPair* __restrict__ pairs, const VoxelGrid g, const double gd1,
+                                                                    const float gd2, const int leaf_pow2, double* __restrict__ partials,
+                                                                    const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks,
+                                                                    const NdtConsts consts, int* __restrict__ done_counter, const int launch) {
   // ---- map this workgroup to (still-active pair, slice).  The launch always has gridDim.x workgroups; they are dealt
   // evenly to the pairs that are still iterating, so a batch whose pairs converge at different iterations keeps the chip
   // busy on the stragglers instead of spinning up empty blocks.  Every wave derives the same mapping from the pairs'
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
   int n_active = 0;
   for (int c0 = 0; c0 < n_pairs; c0 += 64) {
     const int pi = c0 + lane_id;
-    const int a = (pi < n_pairs) ? pairs[pi].active : 0;
+    const int a = (pi < n_pairs) ? (FUSED ? (int)(launch <= pairs[pi].last_launch) : pairs[pi].active) : 0;
     n_active += __popcll(__ballot(a != 0));
   }
   if (n_active == 0) return;
@@ -88,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
     int seen = 0;
     for (int c0 = 0; c0 < n_pairs && pair < 0; c0 += 64) {
       const int pi = c0 + lane_id;
-      const int a = (pi < n_pairs) ? pairs[pi].active : 0;
+      const int a = (pi < n_pairs) ? (FUSED ? (int)(launch <= pairs[pi].last_launch) : pairs[pi].active) : 0;
       unsigned long long m = __ballot(a != 0);
       const int cnt = __popcll(m);
       if (rank < seen + cnt) {
@@ -256,8 +271,24 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_kernel(const float4* c
   if (threadIdx.x < kAccumPad) {
     double v = 0.0;
     if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    partials[((size_t)pair * cap_blocks + slice) * kAccumPad + threadIdx.x] = v;
+    double* row = partials + ((size_t)pair * cap_blocks + slice) * kAccumPad + threadIdx.x;
+    if (FUSED) __hip_atomic_store(row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1): no release fence needed
+    else *row = v;
   }
+  if (!FUSED) return;
+  // ---- publish this slice's row, take a ticket; the workgroup that takes the pair's last ticket closes the evaluation
+  __shared__ int s_last;
+  if (threadIdx.x < kAccumPad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains its stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(&pairs[pair].ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == blocks_per_pair - 1) ? 1 : 0;
+    if (last) pairs[pair].ticket = 0;   // for the next launch (ordered by the kernel boundary)
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  ndt_close_evaluation(pairs + pair, partials + (size_t)pair * cap_blocks * kAccumPad, blocks_per_pair, consts, done_counter, launch);
 }
 
 // Everything below this line -- the validation-mode evaluation, the optimiser (Newton step, More-Thuente state machine,
@@ -488,7 +519,7 @@ __device__ __forceinline__ void trig6(const double* ang, double* sn, double* cs)
 }
 
 template <bool WAVE>
-__device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, const double* x, int need_hessian, bool write_T, bool writer) {
+__device__ __forceinline__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, const double* x, int need_hessian, bool write_T, bool writer) {
   // angles 0..2: the FLOAT-rounded pose angles (transform entries), 3..5: the double pose angles (derivative tables)
   const double ang[6] = {(double)(float)x[3], (double)(float)x[4], (double)(float)x[5], x[3], x[4], x[5]};
   double sn[6], cs[6];
@@ -557,7 +588,7 @@ __device__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, 
 __device__ inline double mt_psi(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
 __device__ inline double mt_dpsi(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
 
-__device__ double mt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
+__device__ __forceinline__ double mt_trial_value(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u, double a_t, double f_t, double g_t) {
   if (f_t > f_l) {
     const double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
     const double w = sqrt(z * z - g_t * g_l);
@@ -583,7 +614,7 @@ __device__ double mt_trial_value(double a_l, double f_l, double g_l, double a_u,
   return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
 }
 
-__device__ bool mt_update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t,
+__device__ __forceinline__ bool mt_update_interval(double& a_l, double& f_l, double& g_l, double& a_u, double& f_u, double& g_u, double a_t, double f_t,
                                    double g_t) {
   if (f_t > f_l) {
     a_u = a_t; f_u = f_t; g_u = g_t;
@@ -607,7 +638,7 @@ __device__ inline double dot6(const double* a, const double* b) {
 
 // Starts one outer iteration from (score, grad, hess) at s.p.  Returns true when an evaluation was queued,
 // false when the iteration finished without one (zero step) or the registration ended.
-__device__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
+__device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
   double neg_g[6], delta[6], rc;
 #pragma unroll
   for (int k = 0; k < 6; k++) neg_g[k] = -s.grad[k];
@@ -658,7 +689,7 @@ __device__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, b
 }
 
 // p += a_t * dir; convergence test of computeTransformation.  Returns true when the registration ended.
-__device__ bool end_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
+__device__ __forceinline__ bool end_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
   const double a = s.a_t;
 #pragma unroll
   for (int k = 0; k < 6; k++) s.p[k] += s.dir[k] * a;
@@ -681,7 +712,7 @@ __device__ inline bool mt_keep_going(const NdtSolver& s, const NdtConsts& c, dou
   return !s.interval_converged && s.step_iterations < c.mt_max_step_iterations && !(psi_t <= 0 && d_phi_t <= -kNu * s.d_phi_0);
 }
 
-__device__ void queue_trial(NdtPair* st, NdtSolver& s, const NdtConsts& c, double a_t, bool writer) {
+__device__ __forceinline__ void queue_trial(NdtPair* st, NdtSolver& s, const NdtConsts& c, double a_t, bool writer) {
   const double step_max = c.step_size, step_min = c.trans_eps / 2;
   a_t = fmax(fmin(a_t, step_max), step_min);
   s.a_t = a_t;
@@ -694,7 +725,7 @@ __device__ void queue_trial(NdtPair* st, NdtSolver& s, const NdtConsts& c, doubl
 
 // Consumes one evaluation result (already stored in s.score/grad/hess) and advances the state machine until
 // the next evaluation is queued or the registration is finished.  Executed by all lanes of one wave in lock step.
-__device__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
+__device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
   s.evaluations++;
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
   switch (s.phase) {
@@ -757,66 +788,93 @@ __device__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool 
   s.phase = PH_DONE;
 }
 
-__global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
-                                                           const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter,
-                                                           const double* __restrict__ strict_totals) {
-  const int pair = blockIdx.x;
-  NdtPair* st = pairs + pair;
-  // Everything this kernel reads was written by the previous launch, i.e. comes from HBM: issue the independent loads (active
-  // flag, slice count, optimiser state) together instead of paying one memory round trip after the other.
-  const int active = st->active;
-  const int blocks_per_pair = pair_blocks[pair];  // slices the derivative launch gave this pair
-  NdtSolver s;
+// Sums a pair's partial rows in slice order and advances its optimiser by one evaluation; executed by one whole workgroup.
+// launch >= 0: fused launches (the pair leaves through last_launch); launch < 0: ndt_solve_kernel (the pair leaves through active).
+__device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch) {
+  __shared__ NdtSolver s_lds;   // the optimiser state lives in LDS: a register copy costs ~150 VGPRs
+  NdtSolver& s = s_lds;
   int need_h = 0;
   if (threadIdx.x < kWave) {
-    s = st->s;
+    s_lds = st->s;
     need_h = st->need_hessian;
   }
-  if (!active) return;
-  __shared__ double tot[kStrictPad];
-  if (strict_totals) {
-    // validation modes: the sums of this evaluation were formed by ndt_strict_reduce / ndt_strict_seqsum
-    if (threadIdx.x < kStrictPad) tot[threadIdx.x] = strict_totals[(size_t)pair * kStrictPad + threadIdx.x];
-    __syncthreads();
+  // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
+  __shared__ double tot[kAccumPad];
+  __shared__ double sm[kBlock / kAccumPad][kAccumPad];
+  const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
+  constexpr int G = kBlock / kAccumPad;
+  double v = 0.0;
+  if (launch >= 0) {   // rows published inside this launch: agent-scope (sc1) loads, never a line this CU may hold from an earlier launch
+    for (int b = grp; b < blocks_per_pair; b += G) v += __hip_atomic_load(partials_of_pair + (size_t)b * kAccumPad + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
-    __shared__ double sm[kBlock / kAccumPad][kAccumPad];
-    const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
-    constexpr int G = kBlock / kAccumPad;
-    double v = 0.0;
-    const double* base = partials + (size_t)pair * cap_blocks * kAccumPad;
-    for (int b = grp; b < blocks_per_pair; b += G) v += base[(size_t)b * kAccumPad + col];
-    sm[grp][col] = v;
-    __syncthreads();
-    if (threadIdx.x < kAccumPad) {
-      double t = 0.0;
-#pragma unroll
-      for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
-      tot[threadIdx.x] = t;
-    }
-    __syncthreads();
+    for (int b = grp; b < blocks_per_pair; b += G) v += partials_of_pair[(size_t)b * kAccumPad + col];
   }
+  sm[grp][col] = v;
+  __syncthreads();
+  if (threadIdx.x < kAccumPad) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
   if (threadIdx.x >= kWave) return;
-  // ---- one wave advances the optimiser: state in registers, every lane computes the same values, lane 0 writes
+  // ---- one wave advances the optimiser: every lane computes the same values, lane 0 writes the pair's record
   const bool writer = threadIdx.x == 0;
   s.score = tot[0];
 #pragma unroll
   for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];
   if (need_h) {
-    if (strict_totals) {
+    int q = 7;
 #pragma unroll
-      for (int k = 0; k < 36; k++) s.hess[k] = tot[7 + k];  // upstream's full 6x6 (not exactly symmetric in float)
-    } else {
-      int q = 7;
+    for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++) {
-          s.hess[i * 6 + j] = tot[q];
-          s.hess[j * 6 + i] = tot[q];
-          q++;
-        }
+      for (int j = i; j < 6; j++) {
+        s.hess[i * 6 + j] = tot[q];
+        s.hess[j * 6 + i] = tot[q];
+        q++;
+      }
+  }
+  ndt_advance(st, s, c, writer);
+  if (writer) {
+    st->s = s;
+    if (s.phase == PH_DONE) {
+      st->active = 0;
+      if (launch >= 0) st->last_launch = launch;
+      atomicAdd(done_counter, 1);
     }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
+                                                           const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter,
+                                                           const double* __restrict__ strict_totals) {
+  const int pair = blockIdx.x;
+  NdtPair* st = pairs + pair;
+  if (!st->active) return;
+  if (!strict_totals) {
+    ndt_close_evaluation(st, partials + (size_t)pair * cap_blocks * kAccumPad, pair_blocks[pair], c, done_counter, -1);
+    return;
+  }
+  // validation modes: the sums of this evaluation were formed by ndt_strict_reduce / ndt_strict_seqsum
+  __shared__ NdtSolver s_lds;
+  NdtSolver& s = s_lds;
+  __shared__ double tot[kStrictPad];
+  int need_h = 0;
+  if (threadIdx.x < kWave) {
+    s_lds = st->s;
+    need_h = st->need_hessian;
+  }
+  if (threadIdx.x < kStrictPad) tot[threadIdx.x] = strict_totals[(size_t)pair * kStrictPad + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  const bool writer = threadIdx.x == 0;
+  s.score = tot[0];
+#pragma unroll
+  for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];
+  if (need_h) {
+#pragma unroll
+    for (int k = 0; k < 36; k++) s.hess[k] = tot[7 + k];  // upstream's full 6x6 (not exactly symmetric in float)
   }
   ndt_advance(st, s, c, writer);
   if (writer) {
@@ -858,6 +916,8 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   for (int k = 0; k < 16; k++) st->final_T[k] = G[k];
   st->s = s;
   st->active = 1;
+  st->last_launch = 0x7FFFFFFF;
+  st->ticket = 0;
 }
 
 struct NdtOut {
@@ -938,7 +998,8 @@ static void launch_strict(dgs_handle* h, const NdtLaunch& L, const dim3 grid, co
                        h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
 }
 
-static void launch_derivatives(dgs_handle* h, const NdtLaunch& L) {
+// launch >= 0: fused launch number `launch` of this align (derivatives + closing workgroups); < 0: derivatives only
+static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -1) {
   const dim3 grid(L.total_blocks), block(kBlock);
   const double gd1 = h->consts.gauss_d1;
   const float gd2 = (float)h->consts.gauss_d2;
@@ -961,24 +1022,25 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L) {
     prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
     return;
   }
-  switch (h->consts.search_method) {
-    case DGS_NDT_DIRECT1:
-      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT1>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
-      break;
-    case DGS_NDT_DIRECT26:
-      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT26>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
-      break;
-    case DGS_NDT_KDTREE:
-      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_KDTREE>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
-      break;
-    default:
-      hipLaunchKernelGGL(ndt_derivatives_kernel<DGS_NDT_DIRECT7>, grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                         gd1, gd2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
-      break;
+#define DGS_LAUNCH_DERIV(SEARCH, FUSED)                                                                                                              \
+  hipLaunchKernelGGL((ndt_derivatives_kernel<SEARCH, FUSED>), grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, gd1, gd2, \
+                     leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts, h->done_counter.ptr, launch)
+  if (launch >= 0) {
+    switch (h->consts.search_method) {
+      case DGS_NDT_DIRECT1: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT1, true); break;
+      case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, true); break;
+      case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, true); break;
+      default: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true); break;
+    }
+  } else {
+    switch (h->consts.search_method) {
+      case DGS_NDT_DIRECT1: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT1, false); break;
+      case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, false); break;
+      case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, false); break;
+      default: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false); break;
+    }
   }
+#undef DGS_LAUNCH_DERIV
   prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
 }
 
@@ -992,8 +1054,10 @@ static void launch_solve(dgs_handle* h, const NdtLaunch& L) {
 static NdtLaunch choose_launch(int n_pairs, int max_n) {
   NdtLaunch L;
   L.n_pairs = n_pairs;
-  L.cap_blocks = std::max(1, std::min((max_n + kBlock - 1) / kBlock, 128));                 // at most 128 slices (partial rows) per pair
-  L.total_blocks = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_blocks, 1024));  // ~4 workgroups per CU
+  static const int env_cap = std::getenv("DGS_NDT_CAP") ? std::atoi(std::getenv("DGS_NDT_CAP")) : 128;          // tuning knobs (sweeps only)
+  static const int env_total = std::getenv("DGS_NDT_BLOCKS") ? std::atoi(std::getenv("DGS_NDT_BLOCKS")) : 1024;
+  L.cap_blocks = std::max(1, std::min((max_n + kBlock - 1) / kBlock, env_cap));             // at most 128 slices (partial rows) per pair
+  L.total_blocks = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_blocks, env_total));  // ~4 workgroups per CU
   L.max_n = std::max(max_n, 1);
   return L;
 }
@@ -1063,10 +1127,16 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   const long max_evals = (long)(h->prm.maximum_iterations + 3) * per_iter + 2;
   const int chunk = 4;  // (derivatives, solve) launches between two looks at the done counter
   long queued = 0;
+  const bool fused = h->ndt_fused && h->consts.strict_order == DGS_NDT_ORDER_FAST;
+  int launch_no = 0;
   auto enqueue_chunk = [&](int slot) -> int {
     for (int e = 0; e < chunk; e++) {
-      launch_derivatives(h, L);
-      launch_solve(h, L);
+      if (fused) {
+        launch_derivatives(h, L, launch_no++);
+      } else {
+        launch_derivatives(h, L);
+        launch_solve(h, L);
+      }
     }
     queued += chunk;
     DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));

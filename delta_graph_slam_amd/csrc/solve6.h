@@ -9,7 +9,7 @@ namespace dgs {
 
 // 6x6 solve by Gauss-Jordan elimination with row pivoting, one matrix element per lane (lanes 0..41 hold [A | b]);
 // every value that steers control flow is wave-uniform.  *rcond receives min|pivot| / max|pivot|.
-__device__ void gj_solve6_wave(const double* A, const double* b, double* x, double* rcond) {
+__device__ __forceinline__ void gj_solve6_wave(const double* A, const double* b, double* x, double* rcond) {
   const int lane = threadIdx.x & 63;
   const int i = (lane < 42) ? lane / 7 : 0, j = (lane < 42) ? lane % 7 : 0;
   double a = 0.0;
@@ -46,9 +46,14 @@ __device__ void gj_solve6_wave(const double* A, const double* b, double* x, doub
 // (6 * eps * s_max).  Slow path: only taken when the elimination above meets a (numerically) singular Hessian -- and the
 // Newton solve of the NDT validation modes (ndt_strict_order), which run it with skip_tol 1e-17 / 60 sweeps: then every
 // operation is the one the CPU checker executes, individually rounded, so the step comes out bit-identical.
-__device__ __noinline__ void svd_solve6_dev(const double* A, const double* b, double* x, const double skip_tol = 4e-16, const int max_sweeps = 40) {
+// U and V live in LDS: the callers run this with every lane of ONE wave computing the same values, so one copy serves the
+// wave (identical stores to one address are harmless), and the 144 VGPRs a register copy costs -- which would set the register
+// allocation, hence the occupancy, of every kernel this function is linked into -- are not needed.
+__device__ __forceinline__ void svd_solve6_dev(const double* A, const double* b, double* x, const double skip_tol = 4e-16, const int max_sweeps = 40) {
 #pragma clang fp contract(off)
-  double U[36], V[36];
+  __shared__ double svd_ws[72];
+  double* U = svd_ws;
+  double* V = svd_ws + 36;
   for (int i = 0; i < 36; i++) { U[i] = A[i]; V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
   for (int sweep = 0; sweep < max_sweeps; sweep++) {
     bool rotated = false;

@@ -227,3 +227,37 @@ def test_very_wide_batch(method):
         assert bool(res[k, 1] > 0.5) == single.hasConverged()
         assert dt <= 1e-5 and dr <= 1e-6, (method, k, dt, dr)
         assert abs(res[k, 2] - single.getFitnessScore()) <= 1e-6 * abs(res[k, 2])
+
+
+def test_fused_launches_equal_launch_pairs_bit_for_bit(scans):
+    """The closing workgroup of a fused launch (DGS_NDT_FUSED=1, default) sums the same rows in the same order as ndt_solve_kernel:
+    transforms, scores, iteration counts and trajectories must be bit-identical to the two-launch form, run after run (a stale row
+    read through the in-launch hand-off would show up as a difference)."""
+    import os
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, _ = scans
+
+    def make(fused):
+        old = os.environ.get("DGS_NDT_FUSED")
+        os.environ["DGS_NDT_FUSED"] = fused
+        try:
+            return Registration("NDT_OMP", ndt_resolution=1.0)
+        finally:
+            if old is None:
+                del os.environ["DGS_NDT_FUSED"]
+            else:
+                os.environ["DGS_NDT_FUSED"] = old
+
+    a, b = make("1"), make("0")
+    a.setInputTarget(tgt)
+    b.setInputTarget(tgt)
+    src = list(sources) * 4           # 24 candidates: uneven finishing times, workgroups re-dealt over the stragglers
+    gs = np.concatenate([guesses] * 4)
+    gs[6:, 0, 3] += np.linspace(-0.3, 0.3, 18).astype(np.float32)
+    ref = b.align_batch(src, gs)
+    for _ in range(4):
+        got = a.align_batch(src, gs)
+        for c, (x, y) in enumerate(zip(got, ref)):
+            assert np.array_equal(x["T"], y["T"]) and x["score"] == y["score"] and x["iterations"] == y["iterations"] and x["evaluations"] == y["evaluations"], c
+            assert x["fitness"] == y["fitness"]
+        assert np.array_equal(a.ndt_trajectory(5), b.ndt_trajectory(5))
