@@ -511,7 +511,7 @@ __device__ __forceinline__ void trig6(const double* ang, double* sn, double* cs)
     double sv, cv;
     sincos(a, &sv, &cv);
 #pragma unroll
-    for (int k = 0; k < 6; k++) { sn[k] = __shfl(sv, k, 64); cs[k] = __shfl(cv, k, 64); }
+    for (int k = 0; k < 6; k++) { sn[k] = readlane_f64(sv, k); cs[k] = readlane_f64(cv, k); }
   } else {
 #pragma unroll
     for (int k = 0; k < 6; k++) sincos(ang[k], &sn[k], &cs[k]);

@@ -7,6 +7,12 @@
 
 namespace dgs {
 
+// value of lane `src` (wave-uniform, known at compile time after unrolling): two v_readlane_b32 instead of the LDS crossbar round
+// trip of a ds_bpermute -- the elimination below is one dependent chain, its latency is the optimiser's latency
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
 // 6x6 solve by Gauss-Jordan elimination with row pivoting, one matrix element per lane (lanes 0..41 hold [A | b]);
 // every value that steers control flow is wave-uniform.  *rcond receives min|pivot| / max|pivot|.
 __device__ __forceinline__ void gj_solve6_wave(const double* A, const double* b, double* x, double* rcond) {
@@ -25,12 +31,12 @@ __device__ __forceinline__ void gj_solve6_wave(const double* A, const double* b,
     double best_v = -1.0;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      const double v = fabs(__shfl(a, r * 7 + k, 64));
+      const double v = fabs(readlane_f64(a, r * 7 + k));
       if (r >= k && v > best_v) { best_v = v; best_r = r; }
     }
     const int src = (i == k) ? best_r * 7 + j : ((i == best_r) ? k * 7 + j : lane);
     a = __shfl(a, src, 64);
-    const double piv = __shfl(a, k * 7 + k, 64);
+    const double piv = readlane_f64(a, k * 7 + k);
     pmax = fmax(pmax, fabs(piv));
     pmin = fmin(pmin, fabs(piv));
     const double rowk = __shfl(a, k * 7 + j, 64);
@@ -38,7 +44,7 @@ __device__ __forceinline__ void gj_solve6_wave(const double* A, const double* b,
     if (piv != 0.0) a = (i == k) ? a / piv : a - colk * (rowk / piv);
   }
 #pragma unroll
-  for (int r = 0; r < 6; r++) x[r] = __shfl(a, r * 7 + 6, 64);
+  for (int r = 0; r < 6; r++) x[r] = readlane_f64(a, r * 7 + 6);
   *rcond = (pmax > 0) ? pmin / pmax : 0.0;
 }
 
