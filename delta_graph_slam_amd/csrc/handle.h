@@ -150,6 +150,7 @@ struct dgs_handle {
   dgs::DevBuf<int> src_sizes;
   dgs::NdtConsts consts{};
   int64_t last_evaluations = 0;
+  bool ndt_pack2 = false;             // DGS_NDT_PACK2=1: DIRECT7 derivatives with two points per lane on packed FP32 (A/B measurements)
   bool ndt_fused = true;              // DGS_NDT_FUSED=0 at dgs_create: (derivatives, solve) launch pairs instead of fused launches
 
   // pinned host staging

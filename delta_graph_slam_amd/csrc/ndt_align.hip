@@ -77,7 +77,16 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
 // which its closing workgroup may write during a launch without changing what the other workgroups of that launch see.
 // __launch_bounds__(kBlock, 4) holds the kernel at the derivative loop's 4 waves per SIMD; the optimiser tail (one workgroup per
 // pair and launch) spills what does not fit.
-template <int SEARCH, bool FUSED>
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f affine_row_rn2(float m0, float m1, float m2, float m3, v2f x, v2f y, v2f z) {
+#pragma clang fp contract(off)
+  return ((m0 * x + m1 * y) + m2 * z) + m3;   // v_pk_mul_f32 / v_pk_add_f32: every element individually rounded, as affine_row_rn
+}
+
+// PACK2: two source points per lane and step, the float fold and projection written on 2-vectors so that they compile to
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two points per instruction); look-ups, the double q = x' - mean, exp and the
+// double accumulation stay per point.  The per-thread order of accumulation is unchanged (i, i + stride, i + 2 stride, ...).
+template <int SEARCH, bool FUSED, bool PACK2>
 __global__ __launch_bounds__(kBlock, 4) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
                                                                     NdtPair* __restrict__ pairs, const VoxelGrid g, const double gd1,
                                                                     const float gd2, const int leaf_pow2, double* __restrict__ partials,
@@ -129,6 +138,120 @@ __global__ __launch_bounds__(kBlock, 4) void ndt_derivatives_kernel(const float4
   for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
 
   const float r2 = g.leaf * g.leaf;
+  if constexpr (PACK2 && SEARCH == DGS_NDT_DIRECT7) {
+    constexpr int NB = 7;
+    const int stride = blocks_per_pair * kBlock;
+    for (int i = slice * kBlock + threadIdx.x; i < n; i += 2 * stride) {
+      const int ib = i + stride;
+      const bool hb = ib < n;
+      const float4 xa = src[i], xb = src[hb ? ib : i];
+      v2f X = {xa.x, xb.x}, Y = {xa.y, xb.y}, Z = {xa.z, xb.z};
+      const v2f xt0 = affine_row_rn2(T[0], T[1], T[2], T[3], X, Y, Z);
+      const v2f xt1 = affine_row_rn2(T[4], T[5], T[6], T[7], X, Y, Z);
+      const v2f xt2 = affine_row_rn2(T[8], T[9], T[10], T[11], X, Y, Z);
+      int vid[2][NB];
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const float a0 = p ? xt0.y : xt0.x, a1 = p ? xt1.y : xt1.x, a2 = p ? xt2.y : xt2.x;
+        const int c0 = (int)floorf(leaf_pow2 ? a0 * g.inv_leaf : a0 / g.leaf);
+        const int c1 = (int)floorf(leaf_pow2 ? a1 * g.inv_leaf : a1 / g.leaf);
+        const int c2 = (int)floorf(leaf_pow2 ? a2 * g.inv_leaf : a2 / g.leaf);
+        const bool interior = c0 > g.min_b[0] && c0 < g.max_b[0] && c1 > g.min_b[1] && c1 < g.max_b[1] && c2 > g.min_b[2] && c2 < g.max_b[2];
+        if (interior && (p == 0 || hb)) {
+          const int* __restrict__ base = g.cell2vox + ((c0 - g.min_b[0]) + (c1 - g.min_b[1]) * g.mul1 + (c2 - g.min_b[2]) * g.mul2);
+#pragma unroll
+          for (int k = 0; k < NB; k++) {
+            int dx, dy, dz;
+            neighbour_offset<SEARCH>(k, dx, dy, dz);
+            vid[p][k] = base[dx + dy * g.mul1 + dz * g.mul2];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NB; k++) {
+            int dx, dy, dz;
+            neighbour_offset<SEARCH>(k, dx, dy, dz);
+            const int b0 = c0 + dx, b1 = c1 + dy, b2 = c2 + dz;
+            const bool inb = (p == 0 || hb) && b0 >= g.min_b[0] && b0 <= g.max_b[0] && b1 >= g.min_b[1] && b1 <= g.max_b[1] && b2 >= g.min_b[2] && b2 <= g.max_b[2];
+            vid[p][k] = inb ? g.cell2vox[(b0 - g.min_b[0]) + (b1 - g.min_b[1]) * g.mul1 + (b2 - g.min_b[2]) * g.mul2] : -1;
+          }
+        }
+      }
+      v2f A[6], M[6], b[3], sc = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 6; k++) { A[k] = (v2f){0.f, 0.f}; M[k] = (v2f){0.f, 0.f}; }
+#pragma unroll
+      for (int k = 0; k < 3; k++) b[k] = (v2f){0.f, 0.f};
+      bool any_a = false, any_b = false;
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const int va = vid[0][k], vb = vid[1][k];
+        if (va < 0 && vb < 0) continue;
+        const float4* __restrict__ ra4 = reinterpret_cast<const float4*>(g.vox + max(va, 0));
+        const float4* __restrict__ rb4 = reinterpret_cast<const float4*>(g.vox + max(vb, 0));
+        const float4 a0 = ra4[0], a1 = ra4[1], a2 = ra4[2], b0 = rb4[0], b1 = rb4[1], b2 = rb4[2];
+        const double mxa = __hiloint2double(__float_as_int(a0.y), __float_as_int(a0.x)), mya = __hiloint2double(__float_as_int(a0.w), __float_as_int(a0.z)),
+                     mza = __hiloint2double(__float_as_int(a1.y), __float_as_int(a1.x));
+        const double mxb = __hiloint2double(__float_as_int(b0.y), __float_as_int(b0.x)), myb = __hiloint2double(__float_as_int(b0.w), __float_as_int(b0.z)),
+                     mzb = __hiloint2double(__float_as_int(b1.y), __float_as_int(b1.x));
+        // a voxel slot that is missing for one of the two points contributes exact zeros for it (q = 0 -> u = 0, w = 0)
+        const v2f q0 = {va >= 0 ? (float)((double)xt0.x - mxa) : 0.f, vb >= 0 ? (float)((double)xt0.y - mxb) : 0.f};
+        const v2f q1 = {va >= 0 ? (float)((double)xt1.x - mya) : 0.f, vb >= 0 ? (float)((double)xt1.y - myb) : 0.f};
+        const v2f q2 = {va >= 0 ? (float)((double)xt2.x - mza) : 0.f, vb >= 0 ? (float)((double)xt2.y - mzb) : 0.f};
+        const v2f Cxx = {a1.z, b1.z}, Cxy = {a1.w, b1.w}, Cxz = {a2.x, b2.x}, Cyy = {a2.y, b2.y}, Cyz = {a2.z, b2.z}, Czz = {a2.w, b2.w};
+        const v2f u0 = q0 * Cxx + q1 * Cxy + q2 * Cxz;
+        const v2f u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
+        const v2f u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
+        const v2f arg = -gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f;
+        v2f e = {expf(arg.x), expf(arg.y)};
+        const float sia = (float)(-gd1 * (double)e.x), sib = (float)(-gd1 * (double)e.y);
+        e = gd2 * e;
+        const bool oka = va >= 0 && !(e.x > 1.f || e.x < 0.f || e.x != e.x), okb = vb >= 0 && !(e.y > 1.f || e.y < 0.f || e.y != e.y);
+        const v2f w = {oka ? (float)((double)e.x * gd1) : 0.f, okb ? (float)((double)e.y * gd1) : 0.f};
+        const v2f wd = w * gd2;
+        sc += (v2f){oka ? sia : 0.f, okb ? sib : 0.f};
+        any_a |= oka;
+        any_b |= okb;
+        b[0] += w * u0; b[1] += w * u1; b[2] += w * u2;
+        A[0] += w * Cxx; A[1] += w * Cxy; A[2] += w * Cxz; A[3] += w * Cyy; A[4] += w * Cyz; A[5] += w * Czz;
+        M[0] += wd * u0 * u0; M[1] += wd * u0 * u1; M[2] += wd * u0 * u2; M[3] += wd * u1 * u1; M[4] += wd * u1 * u2; M[5] += wd * u2 * u2;
+      }
+      if (!any_a && !any_b) continue;
+      // a point without any contributing voxel projects exact zeros (also when its coordinates are not finite)
+      if (!any_a) { X.x = 0.f; Y.x = 0.f; Z.x = 0.f; }
+      if (!any_b) { X.y = 0.f; Y.y = 0.f; Z.y = 0.f; }
+      v2f xj[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) xj[k] = st.jang[k][0] * X + st.jang[k][1] * Y + st.jang[k][2] * Z;
+      const v2f g3 = b[1] * xj[0] + b[2] * xj[1];
+      const v2f g4 = b[0] * xj[2] + b[1] * xj[3] + b[2] * xj[4];
+      const v2f g5 = b[0] * xj[5] + b[1] * xj[6] + b[2] * xj[7];
+#define DGS_ACC2(K, V) { const v2f v_ = (V); acc[K] += (double)v_.x; acc[K] += (double)v_.y; }
+      DGS_ACC2(0, sc) DGS_ACC2(1, b[0]) DGS_ACC2(2, b[1]) DGS_ACC2(3, b[2]) DGS_ACC2(4, g3) DGS_ACC2(5, g4) DGS_ACC2(6, g5)
+      if (need_h) {
+        const v2f N0 = A[0] - M[0], N1 = A[1] - M[1], N2 = A[2] - M[2], N3 = A[3] - M[3], N4 = A[4] - M[4], N5 = A[5] - M[5];
+        const v2f n30 = N1 * xj[0] + N2 * xj[1], n31 = N3 * xj[0] + N4 * xj[1], n32 = N4 * xj[0] + N5 * xj[1];
+        const v2f n40 = N0 * xj[2] + N1 * xj[3] + N2 * xj[4], n41 = N1 * xj[2] + N3 * xj[3] + N4 * xj[4], n42 = N2 * xj[2] + N4 * xj[3] + N5 * xj[4];
+        const v2f n50 = N0 * xj[5] + N1 * xj[6] + N2 * xj[7], n51 = N1 * xj[5] + N3 * xj[6] + N4 * xj[7], n52 = N2 * xj[5] + N4 * xj[6] + N5 * xj[7];
+        v2f xh[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) xh[k] = st.hang[k][0] * X + st.hang[k][1] * Y + st.hang[k][2] * Z;
+        const v2f ba = b[1] * xh[0] + b[2] * xh[1], bb = b[1] * xh[2] + b[2] * xh[3], bc = b[1] * xh[4] + b[2] * xh[5];
+        const v2f bd = b[0] * xh[6] + b[1] * xh[7] + b[2] * xh[8], be = b[0] * xh[9] + b[1] * xh[10] + b[2] * xh[11];
+        const v2f bf = b[0] * xh[12] + b[1] * xh[13] + b[2] * xh[14];
+        DGS_ACC2(7, N0) DGS_ACC2(8, N1) DGS_ACC2(9, N2) DGS_ACC2(10, n30) DGS_ACC2(11, n40) DGS_ACC2(12, n50)
+        DGS_ACC2(13, N3) DGS_ACC2(14, N4) DGS_ACC2(15, n31) DGS_ACC2(16, n41) DGS_ACC2(17, n51)
+        DGS_ACC2(18, N5) DGS_ACC2(19, n32) DGS_ACC2(20, n42) DGS_ACC2(21, n52)
+        DGS_ACC2(22, xj[0] * n31 + xj[1] * n32 + ba)
+        DGS_ACC2(23, xj[0] * n41 + xj[1] * n42 + bb)
+        DGS_ACC2(24, xj[0] * n51 + xj[1] * n52 + bc)
+        DGS_ACC2(25, xj[2] * n40 + xj[3] * n41 + xj[4] * n42 + bd)
+        DGS_ACC2(26, xj[2] * n50 + xj[3] * n51 + xj[4] * n52 + be)
+        DGS_ACC2(27, xj[5] * n50 + xj[6] * n51 + xj[7] * n52 + bf)
+      }
+#undef DGS_ACC2
+    }
+  } else
+  {
   for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
     const float4 x = src[i];
     // pcl::transformPointCloud in float, ((m0 x + m1 y) + m2 z) + m3 with every step rounded (no FMA contraction):
@@ -242,6 +365,8 @@ __global__ __launch_bounds__(kBlock, 4) void ndt_derivatives_kernel(const float4
       acc[26] += (double)(J4[0] * n5[0] + J4[1] * n5[1] + J4[2] * n5[2] + be);
       acc[27] += (double)(J5[0] * n5[0] + J5[1] * n5[1] + J5[2] * n5[2] + bf);
     }
+  }
+
   }
 
   // ---- block reduction.  A DPP butterfly over 28 doubles costs ~900 wave-instructions; instead every wave transposes
@@ -1022,22 +1147,28 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
     prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
     return;
   }
-#define DGS_LAUNCH_DERIV(SEARCH, FUSED)                                                                                                              \
-  hipLaunchKernelGGL((ndt_derivatives_kernel<SEARCH, FUSED>), grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, gd1, gd2, \
+#define DGS_LAUNCH_DERIV(SEARCH, FUSED, PACK)                                                                                                            \
+  hipLaunchKernelGGL((ndt_derivatives_kernel<SEARCH, FUSED, PACK>), grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, gd1, gd2, \
                      leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts, h->done_counter.ptr, launch)
   if (launch >= 0) {
     switch (h->consts.search_method) {
-      case DGS_NDT_DIRECT1: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT1, true); break;
-      case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, true); break;
-      case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, true); break;
-      default: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true); break;
+      case DGS_NDT_DIRECT1: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT1, true, false); break;
+      case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, true, false); break;
+      case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, true, false); break;
+      default:
+        if (h->ndt_pack2) DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true, true);
+        else DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true, false);
+        break;
     }
   } else {
     switch (h->consts.search_method) {
-      case DGS_NDT_DIRECT1: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT1, false); break;
-      case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, false); break;
-      case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, false); break;
-      default: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false); break;
+      case DGS_NDT_DIRECT1: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT1, false, false); break;
+      case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, false, false); break;
+      case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, false, false); break;
+      default:
+        if (h->ndt_pack2) DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false, true);
+        else DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false, false);
+        break;
     }
   }
 #undef DGS_LAUNCH_DERIV

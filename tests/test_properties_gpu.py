@@ -261,3 +261,31 @@ def test_fused_launches_equal_launch_pairs_bit_for_bit(scans):
             assert np.array_equal(x["T"], y["T"]) and x["score"] == y["score"] and x["iterations"] == y["iterations"] and x["evaluations"] == y["evaluations"], c
             assert x["fitness"] == y["fitness"]
         assert np.array_equal(a.ndt_trajectory(5), b.ndt_trajectory(5))
+
+
+def test_packed_fp32_derivative_path_matches_the_default(scans):
+    """DGS_NDT_PACK2=1 (two points per lane on v_pk_* instructions; measured slower, kept for the record -- DESIGN.md) evaluates the
+    same expressions in the same per-thread order: score / gradient / Hessian agree to rounding, aligns take the same iterations."""
+    import os
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, _ = scans
+    old = os.environ.get("DGS_NDT_PACK2")
+    os.environ["DGS_NDT_PACK2"] = "1"
+    try:
+        p = Registration("NDT_OMP", ndt_resolution=1.0)
+    finally:
+        if old is None:
+            del os.environ["DGS_NDT_PACK2"]
+        else:
+            os.environ["DGS_NDT_PACK2"] = old
+    d = Registration("NDT_OMP", ndt_resolution=1.0)
+    for r in (p, d):
+        r.setInputTarget(tgt)
+        r.setInputSource(sources[0][:65001])          # odd count: the second point of the last pair is missing
+    for pose in ([0.3, -0.2, 0.05, 0.01, -0.02, 0.04], [5.0, 1.0, 0.0, 0.0, 0.0, 0.3]):
+        sp, gp, Hp = p.ndt_derivatives(np.array(pose))
+        sd, gd, Hd = d.ndt_derivatives(np.array(pose))
+        assert abs(sp - sd) <= 1e-9 * abs(sd) and np.abs(gp - gd).max() <= 1e-8 * np.abs(gd).max() and np.abs(Hp - Hd).max() <= 1e-8 * np.abs(Hd).max()
+    rp, rd = p.align_batch(sources[:3], guesses[:3]), d.align_batch(sources[:3], guesses[:3])
+    for x, y in zip(rp, rd):
+        assert x["converged"] == y["converged"] and abs(x["iterations"] - y["iterations"]) <= 1
