@@ -179,6 +179,23 @@ def main():
     ms_vox, l_vox = reg.profile_get(L.K_NDT_VOXEL_BUILD)
     reg.profile_enable(False)
 
+    # the same workload through (derivatives, solve) launch pairs: the derivative phase alone, for continuity with round 1's figure
+    os.environ["DGS_NDT_FUSED"] = "0"
+    reg_u = Registration("NDT_OMP", device=local_rank, ndt_resolution=args.resolution, ndt_search_method=L.NDT_SEARCH["DIRECT7"],
+                         transformation_epsilon=0.01, maximum_iterations=64)
+    del os.environ["DGS_NDT_FUSED"]
+    det_u = LoopDetector({"fitness_score_thresh": 1e9}, registration=reg_u)
+    det_u.matching(cands, new_kf)
+    reg_u.profile_enable(True)
+    reg_u.profile_reset()
+    ev_u = 0
+    for _ in range(args.steps):
+        det_u.matching(cands, new_kf)
+        ev_u += reg_u.counts()["evaluations"]
+    ms_u, launches_u = reg_u.profile_get(L.K_NDT_DERIVATIVES)
+    ms_su, launches_su = reg_u.profile_get(L.K_NDT_SOLVE)
+    reg_u.close()
+
     if rank == 0:
         cnt = reg.counts()
         Ns, Nt, V = args.points, cnt["target_points"], cnt["valid_voxels"]
@@ -188,8 +205,13 @@ def main():
         bytes_per_eval = 16 * Ns + 48 * V + 344            # stream source once, table once, 43 doubles out
         total_bytes = ev2 * bytes_per_eval
         achieved = total_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "ndt_derivatives_kernel<DIRECT7>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        ach_u = ev_u * bytes_per_eval / (ms_u * 1e-3) / 1e9 if ms_u > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "ndt_derivatives_kernel<DIRECT7, fused> (derivatives of every active pair + the optimiser step of each pair in "
+                                                     "its closing workgroup)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "derivative_phase_alone": {"kernel": "ndt_derivatives_kernel<DIRECT7> as its own launch (DGS_NDT_FUSED=0, followed by ndt_solve_kernel)",
+                                                      "avg_launch_us": 1e3 * ms_u / max(launches_u, 1), "achieved": ach_u, "frac": ach_u / HBM_PEAK_GBS,
+                                                      "ndt_solve_avg_launch_us": 1e3 * ms_su / max(launches_su, 1)},
                            "avg_launch_us": 1e3 * ms / max(launches, 1), "launches": launches,
                            "algorithmic_bytes_per_launch": total_bytes / max(launches, 1),
                            "bytes_per_evaluation": bytes_per_eval, "valid_voxels": V,
