@@ -413,6 +413,9 @@ __global__ __launch_bounds__(kBlock, 4) void ndt_derivatives_kernel(const float4
   }
   __syncthreads();
   if (!s_last) return;
+#ifdef DGS_CLOSE_STAMPS
+  if (threadIdx.x == 0 && pairs[pair].s.nr_iterations == 1) pairs[pair].traj[kTrajCap - 1][5] = (double)wall_clock64();
+#endif
   ndt_close_evaluation(pairs + pair, partials + (size_t)pair * cap_blocks * kAccumPad, blocks_per_pair, consts, done_counter, launch);
 }
 
@@ -773,6 +776,9 @@ __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtSolver& s, const
     gj_solve6_wave(s.hess, neg_g, delta, &rc);
     if (!(rc > 1e-13)) svd_solve6_dev(s.hess, neg_g, delta);
   }
+#ifdef DGS_CLOSE_STAMPS
+  if (threadIdx.x == 0 && st->s.nr_iterations == 1) st->traj[kTrajCap - 2][0] = (double)wall_clock64();
+#endif
   double norm = sqrt(dot6(delta, delta));
   if (norm == 0 || norm != norm) {
     s.converged = (norm == norm) ? 1 : 0;
@@ -808,7 +814,13 @@ __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtSolver& s, const
   double x[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) x[k] = s.p[k] + s.dir[k] * a_t;
+#ifdef DGS_CLOSE_STAMPS
+  if (threadIdx.x == 0 && st->s.nr_iterations == 1) st->traj[kTrajCap - 2][1] = (double)wall_clock64();
+#endif
   write_evaluation<true>(st, s, c, x, 1, true, writer);
+#ifdef DGS_CLOSE_STAMPS
+  if (threadIdx.x == 0 && st->s.nr_iterations == 1) st->traj[kTrajCap - 2][2] = (double)wall_clock64();
+#endif
   s.phase = PH_MT_FIRST;
   return true;
 }
@@ -915,26 +927,44 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const Ndt
 
 // Sums a pair's partial rows in slice order and advances its optimiser by one evaluation; executed by one whole workgroup.
 // launch >= 0: fused launches (the pair leaves through last_launch); launch < 0: ndt_solve_kernel (the pair leaves through active).
+#ifdef DGS_CLOSE_STAMPS   // diagnostic build only (make dbg): 100 MHz wall-clock stamps of the closing phases into the pair's last trajectory rows
+#define CLOSE_STAMP(k) if (threadIdx.x == 0 && st->s.nr_iterations == 1) st->traj[kTrajCap - 1][k] = (double)wall_clock64();
+#else
+#define CLOSE_STAMP(k)
+#endif
 __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch) {
+  CLOSE_STAMP(0)
   __shared__ NdtSolver s_lds;   // the optimiser state lives in LDS: a register copy costs ~150 VGPRs
   NdtSolver& s = s_lds;
-  int need_h = 0;
-  if (threadIdx.x < kWave) {
-    s_lds = st->s;
-    need_h = st->need_hessian;
-  }
+  // Everything read here comes from memory (the state from the previous launch, the rows from this one): issue it all at once --
+  // the state word by word across the workgroup (one 8-byte load per thread instead of 38 dependent 16-byte loads in every lane
+  // of one wave, which took 5 us of the 7 us this function used to take), the rows as before -- and pay ONE memory latency.
+  static_assert(sizeof(NdtSolver) % 8 == 0 && sizeof(NdtSolver) / 8 <= kBlock, "state words");
+  constexpr int kWords = (int)(sizeof(NdtSolver) / 8);
+  double word = 0.0;
+  if (threadIdx.x < kWords) word = reinterpret_cast<const double*>(&st->s)[threadIdx.x];
+  const int need_h = st->need_hessian;
   // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
   __shared__ double tot[kAccumPad];
   __shared__ double sm[kBlock / kAccumPad][kAccumPad];
   const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
   constexpr int G = kBlock / kAccumPad;
   double v = 0.0;
-  if (launch >= 0) {   // rows published inside this launch: agent-scope (sc1) loads, never a line this CU may hold from an earlier launch
-    for (int b = grp; b < blocks_per_pair; b += G) v += __hip_atomic_load(partials_of_pair + (size_t)b * kAccumPad + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
-    for (int b = grp; b < blocks_per_pair; b += G) v += partials_of_pair[(size_t)b * kAccumPad + col];
+  // four rows in flight per thread, added in slice order (a missing row adds +0.0, which changes nothing)
+  for (int b0 = grp; b0 < blocks_per_pair; b0 += 4 * G) {
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int b = b0 + k * G;
+      const double* ptr = partials_of_pair + (size_t)min(b, blocks_per_pair - 1) * kAccumPad + col;
+      // rows published inside this launch: agent-scope (sc1) loads, never a line this CU may hold from an earlier launch
+      const double x = (launch >= 0) ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+      r[k] = (b < blocks_per_pair) ? x : 0.0;
+    }
+    v = (((v + r[0]) + r[1]) + r[2]) + r[3];
   }
   sm[grp][col] = v;
+  if (threadIdx.x < kWords) reinterpret_cast<double*>(&s_lds)[threadIdx.x] = word;
   __syncthreads();
   if (threadIdx.x < kAccumPad) {
     double t = 0.0;
@@ -943,6 +973,7 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
     tot[threadIdx.x] = t;
   }
   __syncthreads();
+  CLOSE_STAMP(1)
   if (threadIdx.x >= kWave) return;
   // ---- one wave advances the optimiser: every lane computes the same values, lane 0 writes the pair's record
   const bool writer = threadIdx.x == 0;
@@ -960,15 +991,19 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
         q++;
       }
   }
+  CLOSE_STAMP(2)
   ndt_advance(st, s, c, writer);
-  if (writer) {
-    st->s = s;
-    if (s.phase == PH_DONE) {
-      st->active = 0;
-      if (launch >= 0) st->last_launch = launch;
-      atomicAdd(done_counter, 1);
-    }
+  CLOSE_STAMP(3)
+  // write the state back word by word across the wave (lane 0 alone would issue 38 stores one after the other)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS stores have landed
+  for (int w = threadIdx.x; w < kWords; w += kWave) reinterpret_cast<double*>(&st->s)[w] = reinterpret_cast<const double*>(&s_lds)[w];
+  if (writer && s.phase == PH_DONE) {
+    st->active = 0;
+    if (launch >= 0) st->last_launch = launch;
+    atomicAdd(done_counter, 1);
   }
+  CLOSE_STAMP(4)
 }
 
 __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
@@ -1320,7 +1355,11 @@ int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len) {
   DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
   DGS_HIP_TRY(h, hipMemcpy(buf.data(), h->pairs.ptr + pair, sizeof(NdtPair), hipMemcpyDeviceToHost));
   const NdtPair* st = reinterpret_cast<const NdtPair*>(buf.data());
+#ifdef DGS_CLOSE_STAMPS
+  const int n = kTrajCap;
+#else
   const int n = std::min(st->s.traj_len, kTrajCap);
+#endif
   for (int i = 0; i < n; i++)
     for (int k = 0; k < 6; k++) out[i * 6 + k] = st->traj[i][k];
   *len = n;
