@@ -140,3 +140,28 @@ def test_batch_of_many_pairs_matches_single_aligns():
         dt, dr = pose_error(res[k]["T"], single.getFinalTransformation())
         assert dt <= 1e-6 and dr <= 1e-7, (k, dt, dr)
         assert abs(res[k]["fitness"] - single.getFitnessScore()) <= 1e-9 * abs(res[k]["fitness"])
+
+
+def test_cfg4_shard_shape_32_candidates_of_65536_points_fast_gicp(oracle_lib):
+    """configs[3]'s per-GPU shard with FAST_GICP: 32 candidates x 65,536 points as ONE dgs_align_batch (batched LM on the device, k-NN
+    covariances of 33 clouds) against the oracle's sequential loop: same convergence flags and iteration counts, final transforms
+    inside the north-star tolerance on every candidate (the optimiser is double throughout), fitness through the exact NN index."""
+    from delta_graph_slam_amd.registration import Registration
+    from tests.helpers import TOL_ROT, TOL_TRANS, pose_error
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=32, n_points=65536, seed=40, distinct_scans=8)
+    r = Registration("FAST_GICP", gicp_max_correspondence_distance=2.5)
+    r.setInputTarget(tgt)
+    res = r.align_batch(sources, guesses)
+    o = oracle_lib.GicpOracle(max_correspondence_distance=2.5)
+    o.set_target(tgt)
+    worst = [0.0, 0.0]
+    for c in range(0, 32, 3):          # every third candidate on the CPU (11 of 32): the oracle needs ~0.3 s per 65,536-point pair
+        o.set_source(sources[c])
+        ro = o.align(guesses[c])
+        assert res[c]["converged"] == ro["converged"] and res[c]["iterations"] == ro["iterations"], c
+        dt, dr = pose_error(res[c]["T"], ro["T"])
+        assert dt <= TOL_TRANS and dr <= TOL_ROT, (c, dt, dr)
+        worst = [max(worst[0], dt), max(worst[1], dr)]
+        fo, _, _ = oracle_lib.fitness_score(tgt, sources[c], res[c]["T"])
+        assert abs(res[c]["fitness"] - fo) <= 1e-11 * fo
+    assert all(x["status"] == 0 for x in res)
