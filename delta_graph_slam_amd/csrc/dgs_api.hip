@@ -208,6 +208,9 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   h->own_stream = true;
   if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_KNN_LEAF")) h->knn_leaf = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_KNN_MIN_WAVES")) h->knn_min_waves = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("DGS_KNN_ROUNDS")) h->knn_rounds = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DGS_NDT_PACK2")) h->ndt_pack2 = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_GRID_FACTOR")) h->grid_spacing_factor = std::max(0.5f, (float)std::atof(e));
   std::memset(h->final_T, 0, sizeof(h->final_T));

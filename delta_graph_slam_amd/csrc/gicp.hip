@@ -60,18 +60,276 @@ __device__ void regularize_cov(const double* cov9, int method, double* out6) {
   out6[0] = C[0]; out6[1] = C[1]; out6[2] = C[2]; out6[3] = C[4]; out6[4] = C[5]; out6[5] = C[8];
 }
 
-// FastGICP::calculate_covariances: exact k-NN of every point in its own cloud, covariance of the neighbours, regularised
-__global__ __launch_bounds__(kBlock) void gicp_covariance_kernel(const BvhView b, const float4* __restrict__ pts, int n, int k, int method,
-                                                                 double* __restrict__ cov6) {
-  // queries are taken in the index's own (Hilbert) order: the 8 groups of a wave then walk nearly the same nodes
+// FastGICP::calculate_covariances: exact k-NN of every point in its own cloud, covariance of the neighbours, regularised.
+// Two kernels.  (1) gicp_knn_kernel: the search alone, so its registers are the k-NN set and the walk, nothing of the covariance;
+// every wave takes a contiguous stretch of the cloud in the index's own (Hilbert) order, 8 adjacent points per round (the 8
+// groups walk nearly the same nodes), and each round's searches start from a bound on the k-th distance taken from the previous
+// round: all k neighbours of q' lie within r_k(q') + |q - q'| of q (pruning only: same sets).  It writes the set of every
+// point to `nbr` (slot r * 8 + sub of the 8-lane group -> nbr[pos * 32 + slot], -1 = nothing found).  (2)
+// gicp_cov_from_knn_kernel: 8 lanes per point gather the neighbours and reduce mean and covariance in double.
+__global__ __launch_bounds__(kBlock) void gicp_knn_kernel(const BvhView b, const int n, const int k, const int run, int* __restrict__ nbr) {
+  const int sub = threadIdx.x & 7;
+  const int wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  const int first = wave * (8 * run) + ((threadIdx.x & 63) >> 3);
+  float px = 0.f, py = 0.f, pz = 0.f, prev_kth = INFINITY;
+  bool prev_found = false;
+  for (int r = 0; r < run; r++) {
+    const int pos = first + r * 8;
+    if (__all(pos >= n)) break;   // wave-uniform: the stretch is past the end of the cloud
+    const float4 q = (pos < n) ? b.sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int i = (pos < n) ? (int)__float_as_uint(q.w) : -1;
+    const bool alive = pos < n && i >= 0 && i < n;
+    const float bound = nn_warm_bound_round(prev_kth, prev_found, q.x, q.y, q.z, px, py, pz);
+    KnnList L;
+    knn_query_group(b, q.x, q.y, q.z, alive, k, L, bound);
+    const unsigned long long worst = knn_largest(L);
+    prev_kth = __uint_as_float((unsigned)(worst >> 32));
+    prev_found = alive && prev_kth < INFINITY;
+    px = q.x; py = q.y; pz = q.z;
+    if (alive) {
+#pragma unroll
+      for (int s = 0; s < kKnnSlots; s++) {
+        const int slot = s * 8 + sub;
+        if (slot < k) nbr[(size_t)pos * kKnnMax + slot] = (L.dist(s) < INFINITY) ? L.index(s) : -1;
+      }
+    }
+  }
+}
+
+// ---- k-NN sets, one WAVE per leaf of the index (8 Hilbert-adjacent query points), in three cooperative steps:
+//  (a) a window of 8 leaves around the query leaf (64 points, one per lane) gives every query an upper bound T_j on its k-th
+//      squared distance: the k-th smallest of its distances to the window (bit-descent over ballot counts);
+//  (b) ONE walk of the tree for the 8 queries together: a frontier of nodes in LDS, 8 nodes x 8 child boxes per pass, a child
+//      qualifies when it is within T_j of ANY query j (the very test of the per-query walk, so no neighbour can be missed), the
+//      qualifying leaves end up in an LDS list (<= kLeafCap; typical 15-20);
+//  (c) per query: distances to all candidate points (lane = point), the k smallest (distance, index) keys selected by the same
+//      bit-descent, ties at the k-th distance broken towards the lower index, and written to nbr.
+// The sets are the same as those of the per-query walk (knn_query_group): same float distance, same order relation.  Per wave this
+// is ~10 k instructions instead of ~50 k (there, every one of ~40 insertions per query costs ~65 instructions of cross-lane
+// minimum / replace-the-largest).
+// Sparse corners of a cloud (0.7 % of the leaves of a 64-beam scan) have window bounds so loose that the lists overflow.  Those
+// waves retry with the bounds scaled down (s T_j): whatever s, a query whose candidates hold >= k points within s T_j has its
+// exact answer among them (every point within s T_j sits in a gathered leaf); s is bisected between "overflows" and "too few
+// points" until every query of the leaf is answered.  Only what still fails after kKnnRetries -- or is irregular: fewer than 8
+// leaves, a non-finite point in the window, fewer than k finite window points -- takes the per-query walk.
+constexpr int kLeafCap = 64, kFrontCap = 64, kLeafChunks = kLeafCap / 8, kKnnRetries = 12;
+constexpr unsigned kInfBits = 0x7F800000u;
+
+__device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int lanes_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); }
+
+// k-th smallest (1-based) of the wave's values d[0 .. chunks) (bit patterns of non-negative floats, kInfBits = none), built from
+// the top bit down: V keeps the largest prefix with fewer than k values below it.  If some prefix has EXACTLY k values below it
+// the descent stops there and returns it with lt_only = true: then { d < V } is the answer set and ties cannot matter.
+template <int NC>
+__device__ __forceinline__ unsigned kth_smallest_bits(const unsigned (&d)[NC], const int chunks, const int k, bool& lt_only) {
+  unsigned V = 0;
+  lt_only = false;
+#pragma unroll 1
+  for (int bit = 30; bit >= 0; bit--) {
+    const unsigned trial = V | (1u << bit);
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+      if (c < chunks) cnt += __popcll(__ballot(d[c] < trial));
+    if (cnt == k) { lt_only = true; return trial; }
+    if (cnt < k) V = trial;
+  }
+  return V;
+}
+
+// step (b): the leaves within Tl[j] * scale of any query j of `open`; returns their number, or -1 when a list overflowed
+__device__ __forceinline__ int knn_gather_leaves(const BvhView& b, const float4 wp, const int w0, const int n_q, const unsigned open, const float Tl,
+                                                 const float scale, int (*front)[kFrontCap], int* leaves) {
+  const int lane = threadIdx.x & 63;
+  int cur = 0, count = 1;
+  if (lane == 0) front[0][0] = 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  for (int level = 0; level < b.depth; level++) {
+    const bool last = level == b.depth - 1;
+    int next = 0;
+    for (int base = 0; base < count; base += 8) {
+      const int slot = base + (lane >> 3);
+      const bool valid = slot < count;
+      const int node = valid ? front[cur][slot] : 0;
+      const unsigned ofs = (unsigned)node * kFan + (lane & 7);
+      const float4 lo = load16_at(b.box_lo, ofs), hi = load16_at(b.box_hi, ofs);
+      bool hit = false;
+#pragma unroll 1
+      for (int j = 0; j < n_q; j++) {
+        if (!((open >> j) & 1u)) continue;
+        const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
+        hit = hit || (aabb_sqdist_rn(lo, hi, qx, qy, qz) <= readlane_f32(Tl, j) * scale);
+      }
+      hit = hit && valid;
+      const unsigned long long m = __ballot(hit);
+      const int pos = next + lanes_below(m);
+      const int child = node * kFan + 1 + (lane & 7);
+      if (hit) {
+        if (last) { if (pos < kLeafCap) leaves[pos] = child - b.first_leaf; }
+        else if (pos < kFrontCap) front[cur ^ 1][pos] = child;
+      }
+      next += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (next > (last ? kLeafCap : kFrontCap)) return -1;
+    cur ^= 1;
+    count = next;
+  }
+  return count;
+}
+
+__global__ __launch_bounds__(kBlock) void gicp_knn_leaf_kernel(const BvhView b, const int n, const int k, int* __restrict__ nbr, int* __restrict__ stats) {
+  __shared__ int s_front[kBlock / kWave][2][kFrontCap];
+  __shared__ int s_leaves[kBlock / kWave][kLeafCap];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n_leaves = (n + kLeaf - 1) / kLeaf;
+  const int l = blockIdx.x * (kBlock / kWave) + wv;   // this wave's query leaf (wave-uniform)
+  if (l >= n_leaves) return;
+  bool fast = n_leaves >= 8;
+  // ---- (a) window of 8 leaves, one point per lane; the queries are lanes w0 + j
+  const int start = fast ? min(max(l - 3, 0), n_leaves - 8) : 0;
+  const int w0 = fast ? (l - start) * 8 : 0;
+  float4 wp = make_float4(NAN, NAN, NAN, __uint_as_float(0xFFFFFFFFu));
+  if (fast) wp = load16_at(b.sorted, (unsigned)(start * 8 + lane));
+  const bool wreal = fast && (start * 8 + lane) < n;
+  const bool wfinite = wreal && (wp.x - wp.x == 0.f) && (wp.y - wp.y == 0.f) && (wp.z - wp.z == 0.f);
+  if (__ballot(wreal && !wfinite) != 0ull) fast = false;   // a non-finite point nearby: the careful path
+  const int n_q = min(kLeaf, n - l * kLeaf);                // queries of this leaf (the last leaf may be partial)
+  float Tl = 0.f;   // lane j holds T_j
+  if (fast) {
+#pragma unroll 1
+    for (int j = 0; j < n_q; j++) {
+      const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
+      const float dp = sqdist_rn(qx, qy, qz, wp.x, wp.y, wp.z);
+      unsigned d[1] = {(wfinite && dp < INFINITY) ? __float_as_uint(dp) : kInfBits};
+      if (__popcll(__ballot(d[0] < kInfBits)) < k) { fast = false; break; }
+      bool lt;
+      const unsigned V = kth_smallest_bits<1>(d, 1, k, lt);
+      if (lane == j) Tl = __uint_as_float(V);   // lt: the k-th smallest is below V; else it is V -- an upper bound either way
+    }
+  }
+  unsigned open = (1u << n_q) - 1u;
+  int iters = 0;
+  if (fast) {
+    float scale = 1.f, s_small = 0.f, s_over = 0.f;   // s_small: answered nobody new; s_over: overflowed (0 = not seen yet)
+    for (; open != 0u && iters < kKnnRetries; iters++) {
+      const int n_cand = knn_gather_leaves(b, wp, w0, n_q, open, Tl, scale, s_front[wv], s_leaves[wv]);
+      if (n_cand < 0) {
+        s_over = scale;
+        scale = (s_small > 0.f) ? sqrtf(s_small * s_over) : scale * 0.0625f;
+        continue;
+      }
+      // ---- (c) candidates: chunk c = leaves c * 8 .. c * 8 + 7 of the list, lane -> (leaf lane / 8, point lane % 8)
+      const int chunks = (n_cand + 7) >> 3;
+      float4 cp[kLeafChunks];
+#pragma unroll
+      for (int c = 0; c < kLeafChunks; c++) {
+        cp[c] = make_float4(NAN, NAN, NAN, __uint_as_float(0xFFFFFFFFu));
+        if (c < chunks) {
+          const int li = c * 8 + (lane >> 3);
+          if (li < n_cand) cp[c] = load16_at(b.sorted, (unsigned)(s_leaves[wv][li] * kLeaf + (lane & 7)));
+        }
+      }
+      const unsigned was_open = open;
+#pragma unroll 1
+      for (int j = 0; j < n_q; j++) {
+        if (!((open >> j) & 1u)) continue;
+        const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
+        const unsigned Ttry = __float_as_uint(readlane_f32(Tl, j) * scale);
+        unsigned d[kLeafChunks];
+        int within = 0;
+#pragma unroll
+        for (int c = 0; c < kLeafChunks; c++) {
+          d[c] = kInfBits;
+          if (c < chunks) {
+            const float dp = sqdist_rn(qx, qy, qz, cp[c].x, cp[c].y, cp[c].z);   // NaN for padding / empty lanes
+            if (dp < INFINITY && (int)__float_as_uint(cp[c].w) >= 0) d[c] = __float_as_uint(dp);
+            within += __popcll(__ballot(d[c] <= Ttry));
+          }
+        }
+        if (within < k) continue;   // the scaled bound was too small for this query: nothing can be concluded
+        bool lt;
+        const unsigned V = kth_smallest_bits<kLeafChunks>(d, chunks, k, lt);
+        // selection: everything below V; if V IS the k-th smallest, the k - (count below) lowest indices among the values equal to V
+        bool sel[kLeafChunks];
+        int below = 0, equal = 0;
+#pragma unroll
+        for (int c = 0; c < kLeafChunks; c++) {
+          sel[c] = c < chunks && d[c] < V;
+          if (c < chunks) { below += __popcll(__ballot(d[c] < V)); equal += __popcll(__ballot(d[c] == V)); }
+        }
+        if (!lt) {
+          const int need = k - below;
+          if (equal == need) {
+#pragma unroll
+            for (int c = 0; c < kLeafChunks; c++) sel[c] = c < chunks && d[c] <= V;
+          } else {
+            // more values at the k-th distance than places left: lowest index first (rare: duplicate or symmetric points)
+            for (int t = 0; t < need; t++) {
+              int mine = 0x7FFFFFFF;
+#pragma unroll
+              for (int c = 0; c < kLeafChunks; c++)
+                if (c < chunks && d[c] == V && !sel[c]) mine = min(mine, (int)__float_as_uint(cp[c].w));
+              int best = mine;
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+#pragma unroll
+              for (int c = 0; c < kLeafChunks; c++)
+                if (c < chunks && d[c] == V && (int)__float_as_uint(cp[c].w) == best) sel[c] = true;
+            }
+          }
+        }
+        int* __restrict__ out = nbr + (size_t)(l * kLeaf + j) * kKnnMax;
+        int written = 0;
+#pragma unroll
+        for (int c = 0; c < kLeafChunks; c++) {
+          if (c < chunks) {
+            const unsigned long long m = __ballot(sel[c]);
+            if (sel[c]) out[written + lanes_below(m)] = (int)__float_as_uint(cp[c].w);
+            written += __popcll(m);
+          }
+        }
+        open &= ~(1u << j);
+      }
+      if (open != 0u) {
+        if (open != was_open) s_over = 0.f;   // fewer queries now: what overflowed before may fit
+        s_small = scale;
+        scale = (s_over > 0.f) ? sqrtf(s_small * s_over) : fminf(1.f, scale * 4.f);
+      }
+    }
+  }
+#ifdef DGS_KNN_STATS
+  if (lane == 0) { atomicAdd(&stats[0], 1); atomicAdd(&stats[1], (fast && open == 0u) ? 1 : 0); atomicAdd(&stats[2], iters); atomicAdd(&stats[3], iters > 1 ? 1 : 0); }
+#endif
+  if (fast && open == 0u) return;
+  // ---- the careful path: the per-query walk, 8 lanes per query
+  {
+    const int sub = lane & 7, pos = l * kLeaf + (lane >> 3);
+    const float4 q = (pos < n) ? b.sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int i = (pos < n) ? (int)__float_as_uint(q.w) : -1;
+    const bool alive = pos < n && i >= 0 && i < n;
+    KnnList L;
+    knn_query_group(b, q.x, q.y, q.z, alive, k, L);
+    if (alive) {
+#pragma unroll
+      for (int s = 0; s < kKnnSlots; s++) {
+        const int slot = s * 8 + sub;
+        if (slot < k) nbr[(size_t)pos * kKnnMax + slot] = (L.dist(s) < INFINITY) ? L.index(s) : -1;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gicp_cov_from_knn_kernel(const BvhView b, const float4* __restrict__ pts, const int n, const int k, const int method,
+                                                                   const int* __restrict__ nbr, double* __restrict__ cov6) {
   const int sub = threadIdx.x & 7;
   const int pos = (blockIdx.x * kBlock + threadIdx.x) >> 3;
-  const float4 q = (pos < n) ? b.sorted[pos] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int i = (pos < n) ? (int)__float_as_uint(q.w) : -1;
-  const bool alive = pos < n && i >= 0 && i < n;
-  KnnList L;
-  knn_query_group(b, q.x, q.y, q.z, alive, k, L);
-  if (!alive) return;
+  if (pos >= n) return;
+  const int i = (int)__float_as_uint(b.sorted[pos].w);
+  if (i < 0 || i >= n) return;
   // neighbours of this lane (slots r * 8 + sub < k); slots that found nothing are zero columns, as upstream's matrix
   double px[kKnnSlots], py[kKnnSlots], pz[kKnnSlots];
   bool use[kKnnSlots];
@@ -79,8 +337,8 @@ __global__ __launch_bounds__(kBlock) void gicp_covariance_kernel(const BvhView b
 #pragma unroll
   for (int r = 0; r < kKnnSlots; r++) {
     use[r] = (r * 8 + sub) < k;
-    const bool found = use[r] && L.dist(r) < INFINITY;
-    const float4 p = found ? pts[L.index(r)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j = use[r] ? nbr[(size_t)pos * kKnnMax + r * 8 + sub] : -1;
+    const float4 p = (j >= 0) ? pts[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     px[r] = p.x; py[r] = p.y; pz[r] = p.z;
     if (use[r]) { sx += px[r]; sy += py[r]; sz += pz[r]; }
   }
@@ -615,11 +873,36 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
   }
   DGS_HIP_TRY(h, c.cov.reserve((size_t)c.n * 6));
   const BvhView v = make_bvh_view(c.bvh);
+  DGS_HIP_TRY(h, h->knn_nbr.reserve((size_t)c.n * kKnnMax));
+  DGS_HIP_TRY(h, h->knn_stats.reserve(4));
+  // rounds per wave: enough waves to fill the chip several times over, and stretches long enough for the warm bounds to pay
+  const int run = (int)std::max<int64_t>(1, std::min<int64_t>(h->knn_rounds, (c.n + 8 * (int64_t)h->knn_min_waves - 1) / (8 * (int64_t)h->knn_min_waves)));
+  const int64_t waves = (c.n + 8 * (int64_t)run - 1) / (8 * (int64_t)run);
   int slot = prof_begin(h, DGS_K_GICP_COVARIANCE);
-  hipLaunchKernelGGL(gicp_covariance_kernel, dim3((unsigned)(((int64_t)c.n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
-                     h->gconsts.k, h->gconsts.regularization, c.cov.ptr);
+  if (h->knn_leaf) {
+    const int64_t n_leaves = (c.n + kLeaf - 1) / kLeaf;
+#ifdef DGS_KNN_STATS
+    (void)hipMemsetAsync(h->knn_stats.ptr, 0, 4 * sizeof(int), h->stream);
+#endif
+    hipLaunchKernelGGL(gicp_knn_leaf_kernel, dim3((unsigned)((n_leaves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, h->stream, v, (int)c.n, h->gconsts.k,
+                       h->knn_nbr.ptr, h->knn_stats.ptr);
+  } else {
+    hipLaunchKernelGGL(gicp_knn_kernel, dim3((unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, h->stream, v, (int)c.n, h->gconsts.k, run,
+                       h->knn_nbr.ptr);
+  }
+  hipLaunchKernelGGL(gicp_cov_from_knn_kernel, dim3((unsigned)(((int64_t)c.n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
+                     h->gconsts.k, h->gconsts.regularization, h->knn_nbr.ptr, c.cov.ptr);
   prof_end(h, DGS_K_GICP_COVARIANCE, slot);
   DGS_HIP_TRY(h, hipGetLastError());
+#ifdef DGS_KNN_STATS
+  if (h->knn_leaf) {
+    int st[4];
+    (void)hipMemcpyAsync(st, h->knn_stats.ptr, sizeof(st), hipMemcpyDeviceToHost, h->stream);
+    (void)hipStreamSynchronize(h->stream);
+    fprintf(stderr, "[knn] n %lld waves %d answered cooperatively %d (%.2f %%) gather rounds per wave %.3f waves that retried %d\n", (long long)c.n, st[0], st[1],
+            100.0 * st[1] / std::max(st[0], 1), (double)st[2] / std::max(st[0], 1), st[3]);
+  }
+#endif
   c.cov_valid = true;
   c.cov_k = h->gconsts.k;
   c.cov_reg = h->gconsts.regularization;

@@ -150,6 +150,11 @@ struct dgs_handle {
   dgs::DevBuf<int> src_sizes;
   dgs::NdtConsts consts{};
   int64_t last_evaluations = 0;
+  dgs::DevBuf<int> knn_nbr;           // k-NN sets of the cloud whose covariances are being made: [position in Hilbert order * 32 + slot]
+  dgs::DevBuf<int> knn_stats;         // debug build (-DDGS_KNN_STATS): waves, waves on the cooperative path, candidate leaves
+  bool knn_leaf = true;               // DGS_KNN_LEAF=0: the per-query k-NN walk (gicp_knn_kernel) instead of the wave-per-leaf search
+  int knn_min_waves = 4096;           // DGS_KNN_MIN_WAVES: ... but never fewer waves than this (4 per SIMD)
+  int knn_rounds = 8;                 // DGS_KNN_ROUNDS: rounds of 8 adjacent queries per wave in gicp_knn_kernel (1 = no warm bounds)
   bool ndt_pack2 = false;             // DGS_NDT_PACK2=1: DIRECT7 derivatives with two points per lane on packed FP32 (A/B measurements)
   bool ndt_fused = true;              // DGS_NDT_FUSED=0 at dgs_create: (derivatives, solve) launch pairs instead of fused launches
 

@@ -298,8 +298,9 @@ __device__ __forceinline__ unsigned long long knn_largest(const KnnList& L) {
 // All 8 lanes of the group end with the same distributed set.  `alive` = false lanes follow the control flow only.
 // Same instruction-lean loop as nn_query_group_t (32-bit pending word for trees of up to 5 levels, FLT_MAX instead of +inf as
 // the open bound so that one compare rejects the inverted boxes of empty slots).
+// `bound`: an upper bound on the squared distance of the k-th neighbour (INFINITY when nothing is known) -- pruning only.
 template <class PT>
-__device__ __forceinline__ void knn_query_group_t(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L) {
+__device__ __forceinline__ void knn_query_group_t(const BvhView& b, float x, float y, float z, bool alive, int k, float bound, KnnList& L) {
   const int lane = threadIdx.x & 63;
   const unsigned sub = lane & 7, gshift = lane & ~7, bit = 1u << sub;
 #pragma unroll
@@ -308,7 +309,8 @@ __device__ __forceinline__ void knn_query_group_t(const BvhView& b, float x, flo
     L.key[r] = (slot < k) ? (((unsigned long long)__float_as_uint(INFINITY) << 32) | (unsigned)(0x7FFFFFFF - slot)) : 0ull;
   }
   unsigned long long worst = knn_largest(L);
-  float td = FLT_MAX;  // min(distance part of `worst`, FLT_MAX): boxes farther than this cannot hold a better point
+  const float open_td = fminf(bound, FLT_MAX);
+  float td = open_td;  // min(distance part of `worst`, bound, FLT_MAX): boxes farther than this cannot hold a better point
   int node = 0, sh = 0;
   const int last_sh = 8 * (b.depth - 1);
   PT pend = 0;
@@ -344,7 +346,7 @@ __device__ __forceinline__ void knn_query_group_t(const BvhView& b, float x, flo
             worst = knn_largest(L);
             if (cand == best || !(cand < worst)) cand = kKnnInvalid;
           }
-          td = fminf(__uint_as_float((unsigned)(worst >> 32)), FLT_MAX);
+          td = fminf(__uint_as_float((unsigned)(worst >> 32)), open_td);
           mask &= (unsigned)(__ballot(d <= td) >> gshift) & 0xFFu;
         }
         fresh = false;
@@ -364,11 +366,11 @@ __device__ __forceinline__ void knn_query_group_t(const BvhView& b, float x, flo
   }
 }
 
-__device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L) {
+__device__ __forceinline__ void knn_query_group(const BvhView& b, float x, float y, float z, bool alive, int k, KnnList& L, float bound = INFINITY) {
   if (b.depth <= 5)
-    knn_query_group_t<unsigned>(b, x, y, z, alive, k, L);
+    knn_query_group_t<unsigned>(b, x, y, z, alive, k, bound, L);
   else
-    knn_query_group_t<unsigned long long>(b, x, y, z, alive, k, L);
+    knn_query_group_t<unsigned long long>(b, x, y, z, alive, k, bound, L);
 }
 
 // host: device view of a built index (nn_bvh.hip)

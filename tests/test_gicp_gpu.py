@@ -165,3 +165,66 @@ def test_cfg4_shard_shape_32_candidates_of_65536_points_fast_gicp(oracle_lib):
         fo, _, _ = oracle_lib.fitness_score(tgt, sources[c], res[c]["T"])
         assert abs(res[c]["fitness"] - fo) <= 1e-11 * fo
     assert all(x["status"] == 0 for x in res)
+
+
+def _raw_covariances(cloud, leaf, k=20):
+    """k-NN covariances without regularisation (the most sensitive read-out of the neighbour sets) by either k-NN search."""
+    import os
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd.registration import Registration
+    old = os.environ.get("DGS_KNN_LEAF")
+    os.environ["DGS_KNN_LEAF"] = "1" if leaf else "0"
+    try:
+        r = Registration("FAST_GICP", gicp_regularization=L.GICP_REG["NONE"], gicp_correspondence_randomness=k)
+    finally:
+        if old is None:
+            del os.environ["DGS_KNN_LEAF"]
+        else:
+            os.environ["DGS_KNN_LEAF"] = old
+    r.setInputTarget(cloud)
+    r.setInputSource(cloud)
+    return r.gicp_covariances("source", cloud.shape[0])
+
+
+def _knn_cases():
+    rng = np.random.default_rng(5)
+    tgt, sources, _, _ = synth.loop_batch(n_candidates=1, n_points=65536, seed=40)
+    yield "hdl64 65,536", tgt, 20
+    yield "vlp16 frame", np.ascontiguousarray(synth.vlp16_stream(n_frames=1)[0][0]), 20
+    yield "indoor 50,000", synth.indoor_pair(n=50000)[0], 20
+    for n in (11, 63, 64, 65, 71, 1000, 4099):          # fewer than 8 leaves, exactly 8, partial last leaf
+        c = np.ones((n, 4), np.float32)
+        c[:, :3] = rng.normal(size=(n, 3)) * 3
+        yield f"gaussian {n}", c, 20
+    c = np.ones((6000, 4), np.float32)
+    c[:, :3] = np.round(rng.normal(size=(6000, 3)) * 4) / 4     # lattice points: many duplicates, many ties at the k-th distance
+    yield "lattice duplicates", c, 20
+    c = np.ones((5000, 4), np.float32)
+    c[:, :3] = rng.normal(size=(5000, 3)) * 2
+    c[rng.choice(5000, 40, replace=False), rng.integers(0, 3, 40)] = np.nan
+    c[rng.choice(5000, 10, replace=False), 0] = np.inf
+    yield "non-finite points", c, 20
+    c = np.ones((3000, 4), np.float32)
+    c[:, 0] = np.linspace(-50, 50, 3000)
+    c[:, 1:3] = 0
+    yield "collinear", c, 20
+    c = np.ones((20000, 4), np.float32)
+    c[:, :3] = rng.normal(size=(20000, 3)) * 0.5
+    c[:200, :3] += 500.0                                   # a far cluster: window bounds of its leaves are huge
+    yield "far cluster", c, 20
+    yield "k = 5", tgt[:30000], 5
+    yield "k = 32", tgt[:30000], 32
+
+
+def test_wave_per_leaf_knn_finds_the_sets_of_the_per_query_walk():
+    """`gicp_knn_leaf_kernel` (one wave per index leaf: window bound, one shared tree walk, rank selection) must produce the
+    neighbour sets of the per-query walk (`DGS_KNN_LEAF=0`) on every kind of cloud, including those that take its careful path.
+    Raw covariances agree to the order of the double sums; a wrong or missing neighbour would show at 1e-3."""
+    for name, cloud, k in _knn_cases():
+        a = _raw_covariances(cloud, True, k)
+        b = _raw_covariances(cloud, False, k)
+        finite = np.isfinite(b).all(axis=(1, 2))
+        assert (np.isfinite(a).all(axis=(1, 2)) == finite).all(), name
+        scale = np.maximum(np.abs(b[finite]).max(axis=(1, 2)), 1e-300)
+        err = np.abs(a[finite] - b[finite]).max(axis=(1, 2)) / scale
+        assert err.max() < 1e-11, (name, float(err.max()), int((err > 1e-11).sum()))
