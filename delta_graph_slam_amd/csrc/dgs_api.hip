@@ -46,7 +46,18 @@ int side_fork(dgs_handle* h) {
   return DGS_OK;
 }
 
+// the deferred build of the target's NN index (dgs_align_batch): enqueue it on the side stream now
+int side_build_now(dgs_handle* h) {
+  if (!h->side_build_deferred) return DGS_OK;
+  h->side_build_deferred = false;
+  int rs = ensure_target_index(h, h->side_stream);
+  if (rs == DGS_OK && hipEventRecord(h->ev_join, h->side_stream) == hipSuccess) h->side_pending = true;
+  if (rs != DGS_OK) { (void)hipStreamSynchronize(h->side_stream); h->tgt->bvh.valid = false; h->tgt_grid.valid = false; }
+  return rs;
+}
+
 int side_join(dgs_handle* h) {
+  if (h->side_build_deferred && side_build_now(h) != DGS_OK) return DGS_ERR_HIP;   // nobody took it up (an early error return)
   if (!h->side_pending) return DGS_OK;
   h->side_pending = false;
   DGS_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -208,6 +219,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   h->own_stream = true;
   if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_KNN_PARTS")) { const int v = std::atoi(e); h->knn_parts = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }
   if (const char* e = std::getenv("DGS_KNN_LEAF")) h->knn_leaf = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_KNN_MIN_WAVES")) h->knn_min_waves = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DGS_KNN_ROUNDS")) h->knn_rounds = std::max(1, std::atoi(e));
@@ -587,11 +599,12 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
   // the fitness pass needs the target's NN index only after the last iteration: build it on the side stream meanwhile
   // (a dozen tiny launches, 0.15 ms on the critical path otherwise); kernels timed one by one stay on one stream
   h->use_grid = grid_wanted(h, total);
+  // The side stream forks HERE (it depends on the target only), but its launches are enqueued by ndt_align_pairs after the first
+  // chunks of iteration launches: enqueueing a dozen launches costs the host ~50 us during which the main stream would sit empty.
   if (compute_fitness && (!h->tgt->bvh.valid || (h->use_grid && !h->tgt_grid.valid)) && !h->prof.enabled) {
     int rs = side_fork(h);
-    if (rs == DGS_OK) rs = ensure_target_index(h, h->side_stream);
-    if (rs == DGS_OK && hipEventRecord(h->ev_join, h->side_stream) == hipSuccess) h->side_pending = true;
-    if (rs != DGS_OK) { (void)hipStreamSynchronize(h->side_stream); h->tgt->bvh.valid = false; h->tgt_grid.valid = false; return rs; }
+    if (rs != DGS_OK) return rs;
+    h->side_build_deferred = true;
   }
   int rc = ndt_align_pairs(h, n, ptrs.data(), sz.data(), guesses16, results);
   if (side_join(h) != DGS_OK && rc == DGS_OK) rc = DGS_ERR_HIP;  // whatever happened above, nothing stays pending

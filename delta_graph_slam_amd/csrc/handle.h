@@ -108,6 +108,7 @@ struct dgs_handle {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_pending = false;
+  bool side_build_deferred = false;   // forked, launches still to be enqueued (side_build_now)
   std::string err;
 
   // clouds (pcl::PointXYZ layout): the handle's own copies, or borrowed dgs_cloud objects
@@ -152,6 +153,7 @@ struct dgs_handle {
   int64_t last_evaluations = 0;
   dgs::DevBuf<int> knn_nbr;           // k-NN sets of the cloud whose covariances are being made: [position in Hilbert order * 32 + slot]
   dgs::DevBuf<int> knn_stats;         // debug build (-DDGS_KNN_STATS): waves, waves on the cooperative path, candidate leaves
+  int knn_parts = 0;                  // DGS_KNN_PARTS: waves per leaf in gicp_knn_leaf_kernel (0 = by cloud size)
   bool knn_leaf = true;               // DGS_KNN_LEAF=0: the per-query k-NN walk (gicp_knn_kernel) instead of the wave-per-leaf search
   int knn_min_waves = 4096;           // DGS_KNN_MIN_WAVES: ... but never fewer waves than this (4 per SIMD)
   int knn_rounds = 8;                 // DGS_KNN_ROUNDS: rounds of 8 adjacent queries per wave in gicp_knn_kernel (1 = no warm bounds)
@@ -209,6 +211,7 @@ int ensure_pinned(dgs_handle* h, size_t bytes);
 int ensure_poll_events(dgs_handle* h);
 int side_fork(dgs_handle* h);   // side_stream continues from what the main stream has enqueued so far
 int side_join(dgs_handle* h);   // the main stream waits for what side_fork()'s work (no-op when nothing is pending)
+int side_build_now(dgs_handle* h);   // enqueues the deferred build of the target's NN index on the side stream
 
 // ndt_voxel.hip
 int ndt_build_target(dgs_handle* h);

@@ -1312,10 +1312,14 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   int cur = 0;
   rc = enqueue_chunk(0);
   bool finished = false;
+  bool first = true;
   while (rc == DGS_OK) {
     const bool more = queued < max_evals;
     if (more) rc = enqueue_chunk(cur ^ 1);
     if (rc != DGS_OK) break;
+    // two chunks are in flight: now the host has time to enqueue what dgs_align_batch left for the side stream
+    if (first && (rc = side_build_now(h)) != DGS_OK) break;
+    first = false;
     hipError_t e = hipEventSynchronize(ev[cur]);
     if (e != hipSuccess) { h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; break; }
     if (flags[cur] >= n_pairs) { finished = true; break; }

@@ -6,8 +6,8 @@ from delta_graph_slam_amd.registration import Registration
 tgt, sources, guesses, gts = synth.loop_batch(n_candidates=4, n_points=65536, seed=40, distinct_scans=4)
 frames = synth.vlp16_stream(n_frames=4)[0]
 for name, clouds in (('hdl64 65,536', [tgt] + list(sources)), ('vlp16', [np.ascontiguousarray(f) for f in frames])):
-    for leaf, rounds, minw in ((1, 0, 0),):
-        os.environ['DGS_KNN_LEAF'] = str(leaf); os.environ['DGS_KNN_ROUNDS'] = str(max(rounds, 1)); os.environ['DGS_KNN_MIN_WAVES'] = str(max(minw, 1))
+    for leaf, rounds, minw in ((1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 0, 0)):
+        os.environ['DGS_KNN_LEAF'] = str(leaf); os.environ['DGS_KNN_PARTS'] = str(rounds) if leaf else '0'; os.environ['DGS_KNN_ROUNDS'] = str(max(rounds, 1)); os.environ['DGS_KNN_MIN_WAVES'] = str(max(minw, 1))
         reg = Registration("FAST_GICP", gicp_max_correspondence_distance=2.0)
         dev = [torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).cuda() for c in clouds]
         reg.setInputTarget(dev[0]); reg.setInputSource(dev[1]); reg.align(np.eye(4, dtype=np.float32))
