@@ -137,14 +137,16 @@ __global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __
   const int off = run_offsets[r];
   double s[3] = {0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0};
   float cf[3] = {0, 0, 0};
-  // upstream's order (point index, one after the other) is kept; the loads of 8 points are issued together so that a voxel
-  // with hundreds of points pays one memory latency per 8 points instead of one per point
-  for (int j0 = 0; j0 < cnt; j0 += 8) {
-    float4 pb[8];
+  // upstream's order (point index, one after the other) is kept; the loads of kBatch points are issued together so that a voxel
+  // with hundreds of points pays one memory latency per kBatch points instead of one per point (the kernel is a few dozen waves:
+  // its duration is the latency chain of the fullest voxel)
+  constexpr int kBatch = 24;
+  for (int j0 = 0; j0 < cnt; j0 += kBatch) {
+    float4 pb[kBatch];
 #pragma unroll
-    for (int u = 0; u < 8; u++) pb[u] = (j0 + u < cnt) ? sorted_pts[off + j0 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < kBatch; u++) pb[u] = (j0 + u < cnt) ? sorted_pts[off + j0 + u] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < kBatch; u++) {
       if (j0 + u < cnt) {
         const float4 p = pb[u];
         const double x = p.x, y = p.y, z = p.z;

@@ -32,8 +32,8 @@ def _is_tensor(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
 
-def _cloud_ptr(cloud):
-    """-> (pointer, n, on_device, keepalive)"""
+def _cloud_ptr(cloud, sync: bool = True):
+    """-> (pointer, n, on_device, keepalive).  sync=False: the caller orders torch's stream itself (once for a whole batch)."""
     if _is_tensor(cloud):
         if cloud.dtype != torch.float32 or cloud.dim() != 2 or cloud.shape[1] != 4:
             raise ValueError("cloud tensors must be float32 [N,4]")
@@ -41,7 +41,8 @@ def _cloud_ptr(cloud):
         if t.is_cuda:
             # the handle works on a stream of its own: whatever produced this tensor on torch's current stream must have finished
             # (include/dgs_reg.h, ordering contract for device pointers); the library is done with the buffer when its call returns
-            torch.cuda.current_stream(t.device).synchronize()
+            if sync:
+                torch.cuda.current_stream(t.device).synchronize()
             return C.c_void_p(t.data_ptr()), t.shape[0], 1, t
         a = t.numpy()
         return a.ctypes.data_as(C.c_void_p), a.shape[0], 0, a
@@ -275,16 +276,21 @@ class Registration:
         sizes = (C.c_int64 * n)()
         keep = []
         devs = set()
+        cuda_devs = set()
         for i, s in enumerate(sources):
-            ptr, m, dev, k = _cloud_ptr(s)
+            ptr, m, dev, k = _cloud_ptr(s, sync=False)
             ptrs[i] = ptr.value if ptr.value else 0
             sizes[i] = m
             keep.append(k)
             if m:
                 devs.add(dev)
+            if dev:
+                cuda_devs.add(k.device)
         if len(devs) > 1:
             raise ValueError("sources must be all host arrays or all device tensors")
         on_device = devs.pop() if devs else 0
+        for d in cuda_devs:   # one ordering point for the whole batch (the device-pointer contract of include/dgs_reg.h)
+            torch.cuda.current_stream(d).synchronize()
         self._check(self._lib.dgs_align_batch(self._h, n, ptrs, sizes, on_device, gp, 1 if compute_fitness else 0, fitness_max_range, res))
         return res
 
