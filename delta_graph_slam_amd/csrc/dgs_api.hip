@@ -37,7 +37,10 @@ int ensure_poll_events(dgs_handle* h) {
 
 int side_fork(dgs_handle* h) {
   if (!h->side_stream) {
-    DGS_HIP_TRY(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    // lowest priority: the side stream's small builds fill what the main stream's launches leave free, never the other way round
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    DGS_HIP_TRY(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_low));
     DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   }
@@ -219,6 +222,8 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   h->own_stream = true;
   if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NN_KD")) h->nn_kd = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NN_KD_ALL")) h->nn_kd_all = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_KNN_PARTS")) { const int v = std::atoi(e); h->knn_parts = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }
   if (const char* e = std::getenv("DGS_KNN_LEAF")) h->knn_leaf = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_KNN_MIN_WAVES")) h->knn_min_waves = std::max(1, std::atoi(e));
@@ -599,6 +604,10 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
   // the fitness pass needs the target's NN index only after the last iteration: build it on the side stream meanwhile
   // (a dozen tiny launches, 0.15 ms on the critical path otherwise); kernels timed one by one stay on one stream
   h->use_grid = grid_wanted(h, total);
+  // an index built for this batch is k-d ordered: the build (a sort per level) hides behind the iterations, the fitness pass over
+  // n x 65,536 queries is twice as fast as over the Hilbert order (nn_bvh.hip)
+  struct KdScope { dgs_handle* h; ~KdScope() { h->batch_kd = false; } } kd_scope{h};
+  h->batch_kd = h->nn_kd && compute_fitness;
   // The side stream forks HERE (it depends on the target only), but its launches are enqueued by ndt_align_pairs after the first
   // chunks of iteration launches: enqueueing a dozen launches costs the host ~50 us during which the main stream would sit empty.
   if (compute_fitness && (!h->tgt->bvh.valid || (h->use_grid && !h->tgt_grid.valid)) && !h->prof.enabled) {

@@ -27,6 +27,9 @@ struct Bvh {
   DevBuf<float4> node_hi;
   DevBuf<uint32_t> keys, keys_alt;
   DevBuf<uint32_t> vals, vals_alt;
+  DevBuf<unsigned long long> kd_keys, kd_keys_alt;   // k-d order build: (range, coordinate) keys of the global levels
+  DevBuf<unsigned> kd_bbox;                          // ... and the boxes of the ranges of the current level
+  bool kd = false;          // points are in k-d (median split) order instead of Hilbert order
   bool valid = false;
 };
 
@@ -84,6 +87,7 @@ struct CloudState {
     pts.release(); cov.release();
     bvh.sorted.release(); bvh.node_lo.release(); bvh.node_hi.release();
     bvh.keys.release(); bvh.keys_alt.release(); bvh.vals.release(); bvh.vals_alt.release();
+    bvh.kd_keys.release(); bvh.kd_keys_alt.release(); bvh.kd_bbox.release();
     n = 0;
     invalidate();
   }
@@ -153,6 +157,9 @@ struct dgs_handle {
   int64_t last_evaluations = 0;
   dgs::DevBuf<int> knn_nbr;           // k-NN sets of the cloud whose covariances are being made: [position in Hilbert order * 32 + slot]
   dgs::DevBuf<int> knn_stats;         // debug build (-DDGS_KNN_STATS): waves, waves on the cooperative path, candidate leaves
+  bool nn_kd = true;                  // DGS_NN_KD=0: Hilbert order also for the loop batch's target index
+  bool nn_kd_all = false;             // DGS_NN_KD_ALL=1: every target index is k-d ordered (tests of the k-d build through the single-query hooks)
+  bool batch_kd = false;              // set by dgs_align_batch* around its work: the target index it builds is k-d ordered
   int knn_parts = 0;                  // DGS_KNN_PARTS: waves per leaf in gicp_knn_leaf_kernel (0 = by cloud size)
   bool knn_leaf = true;               // DGS_KNN_LEAF=0: the per-query k-NN walk (gicp_knn_kernel) instead of the wave-per-leaf search
   int knn_min_waves = 4096;           // DGS_KNN_MIN_WAVES: ... but never fewer waves than this (4 per SIMD)
@@ -224,7 +231,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs_
 int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len);
 int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36);
 // nn_bvh.hip
-int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n, hipStream_t st = nullptr);  // st: default the handle's stream
+int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n, hipStream_t st = nullptr, bool kd_order = false);  // st: default the handle's stream; kd_order: median-split order (slower build, faster queries)
 int nn_fitness(dgs_handle* h, const float4* src, int64_t n, const float* T16, double max_range, double inlier_sq,
                double* sum, int64_t* count, int64_t* inliers);
 // batched: device arrays of source pointers / sizes, device transforms (column-major 16 floats every T_stride_bytes)

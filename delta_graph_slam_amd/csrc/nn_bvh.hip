@@ -24,6 +24,8 @@
 #include <cfloat>
 #include <cmath>
 
+#include <vector>
+#include <cstdio>
 #include "handle.h"
 #include "nn_group.h"
 
@@ -56,6 +58,219 @@ __global__ __launch_bounds__(kBlock) void gather_index_kernel(const float4* __re
     out[i] = p;
   } else {
     out[i] = make_float4(NAN, NAN, NAN, __uint_as_float(0xFFFFFFFFu));  // padding: distance is NaN, never selected
+  }
+}
+
+// ---- k-d order: the same implicit tree over a point order made by median splits ------------------------------
+// With the Hilbert order a node's 8 children are runs of the curve: compact, but their boxes overlap (a query within reach of
+// 3.3 nodes per level on a 64-beam scan).  Splitting every range at its middle rank along its widest axis, three times per
+// 8-ary level, gives boxes that do not overlap along the split axes: 1.2-2.7 nodes per level, and the fitness pass over 32 x
+// 65,536 queries drops from 0.83 to 0.45 ms (same results: any order of the points gives a correct tree).  The price is the
+// build -- a sort per binary level instead of one sort -- so this order is used where the build hides behind other work (the
+// loop-closure batch builds the target's index on the side stream while the candidates iterate).
+//
+// The tree's layout fixes the ranks: a range of W = 8 * 2^m slots splits at slot W / 2; the cloud fills the slots from the
+// left, so every range is full except the last.  Levels with W > kKdChunk are one global radix sort each on the key
+// (range number, coordinate along the range's widest axis); from W = kKdChunk down one workgroup per chunk sorts in LDS.
+constexpr int kKdChunk = 4096, kKdThreads = 1024, kKdPer = kKdChunk / kKdThreads;
+
+__device__ __forceinline__ unsigned orderable_f32(float f) {   // monotone float -> unsigned (finite values and infinities)
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ bool finite3(const float4 p) { return (p.x - p.x == 0.f) && (p.y - p.y == 0.f) && (p.z - p.z == 0.f); }
+// widest axis of a box given as orderable minima [0..2] and maxima [3..5]; an empty box (no finite point) -> axis 0
+__device__ __forceinline__ int widest_axis(const unsigned* bb) {
+  if (bb[0] > bb[3]) return 0;
+  // extents compared as floats recovered from the orderable form
+  float e[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const unsigned lo = bb[a], hi = bb[3 + a];
+    const float flo = __uint_as_float((lo & 0x80000000u) ? (lo & 0x7FFFFFFFu) : ~lo), fhi = __uint_as_float((hi & 0x80000000u) ? (hi & 0x7FFFFFFFu) : ~hi);
+    e[a] = fhi - flo;
+  }
+  return (e[0] >= e[1] && e[0] >= e[2]) ? 0 : (e[1] >= e[2] ? 1 : 2);
+}
+
+__global__ __launch_bounds__(kBlock) void kd_iota_kernel(uint32_t* __restrict__ vals, int n, unsigned* __restrict__ bbox, int n_seg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) vals[i] = (uint32_t)i;
+  if (i < n_seg * 6) bbox[i] = (i % 6 < 3) ? 0xFFFFFFFFu : 0u;
+}
+
+// boxes of the ranges of W slots (W >= kBlock: a workgroup's points belong to one range): wave reduction, one LDS atomic per wave
+// and value, one global atomic per workgroup and value (minima / maxima: the result does not depend on the order)
+__global__ __launch_bounds__(kBlock) void kd_bbox_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ vals, int n, int W,
+                                                         unsigned* __restrict__ bbox) {
+  __shared__ unsigned sm[6];
+  if (threadIdx.x < 6) sm[threadIdx.x] = (threadIdx.x < 3) ? 0xFFFFFFFFu : 0u;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned v[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  if (i < n) {
+    const float4 p = pts[vals[i]];
+    if (finite3(p)) {
+      v[0] = v[3] = orderable_f32(p.x);
+      v[1] = v[4] = orderable_f32(p.y);
+      v[2] = v[5] = orderable_f32(p.z);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) v[k] = min(v[k], (unsigned)__shfl_xor((int)v[k], o));
+#pragma unroll
+    for (int k = 3; k < 6; k++) v[k] = max(v[k], (unsigned)__shfl_xor((int)v[k], o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) atomicMin(&sm[k], v[k]);
+#pragma unroll
+    for (int k = 3; k < 6; k++) atomicMax(&sm[k], v[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    unsigned* dst = bbox + (size_t)((blockIdx.x * blockDim.x) / W) * 6 + threadIdx.x;
+    if (threadIdx.x < 3) atomicMin(dst, sm[threadIdx.x]); else atomicMax(dst, sm[threadIdx.x]);
+  }
+}
+
+// key = (range number, coordinate along the range's widest axis); non-finite points go to the end of their range
+__global__ __launch_bounds__(kBlock) void kd_key_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ vals, int n, int W,
+                                                        const unsigned* __restrict__ bbox, unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int seg = i / W;
+  const float4 p = pts[vals[i]];
+  unsigned bb[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) bb[k] = bbox[(size_t)seg * 6 + k];
+  const int axis = widest_axis(bb);
+  const float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+  const unsigned ck = finite3(p) ? orderable_f32(c) : 0xFFFFFFFFu;
+  keys[i] = ((unsigned long long)(unsigned)seg << 32) | ck;
+}
+
+__global__ __launch_bounds__(kBlock) void kd_clear_bbox_kernel(unsigned* __restrict__ bbox, int n_seg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seg * 6) bbox[i] = (i % 6 < 3) ? 0xFFFFFFFFu : 0u;
+}
+
+// the levels from W = kKdChunk down to W = 16 (-> leaves of 8) for one chunk of kKdChunk slots: bitonic sorts in LDS of
+// (coordinate along the range's widest axis, point index) -- the index makes the order total, hence deterministic
+__global__ __launch_bounds__(kKdThreads) void kd_local_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ vals_in,
+                                                              uint32_t* __restrict__ vals_out, int n) {
+  __shared__ unsigned s_key[kKdChunk];
+  __shared__ uint32_t s_idx[kKdChunk];
+  __shared__ unsigned s_bb[kKdChunk / 16][6];
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kKdChunk;
+  const int cnt = min(kKdChunk, n - base);
+#pragma unroll
+  for (int r = 0; r < kKdPer; r++) {
+    const int e = tid + r * kKdThreads;
+    s_idx[e] = (e < cnt) ? vals_in[base + e] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  for (int W = kKdChunk; W >= 16; W >>= 1) {
+    const int n_seg = kKdChunk / W;
+    for (int t = tid; t < n_seg * 6; t += kKdThreads) s_bb[t / 6][t % 6] = (t % 6 < 3) ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    float4 p[kKdPer];
+    bool fin[kKdPer];
+#pragma unroll
+    for (int r = 0; r < kKdPer; r++) {
+      const int e = tid + r * kKdThreads;
+      const uint32_t gi = s_idx[e];
+      p[r] = (gi != 0xFFFFFFFFu) ? pts[gi] : make_float4(NAN, NAN, NAN, 0.f);
+      fin[r] = gi != 0xFFFFFFFFu && finite3(p[r]);
+      unsigned v[6] = {fin[r] ? orderable_f32(p[r].x) : 0xFFFFFFFFu, fin[r] ? orderable_f32(p[r].y) : 0xFFFFFFFFu, fin[r] ? orderable_f32(p[r].z) : 0xFFFFFFFFu,
+                       fin[r] ? orderable_f32(p[r].x) : 0u, fin[r] ? orderable_f32(p[r].y) : 0u, fin[r] ? orderable_f32(p[r].z) : 0u};
+      if (W >= kWave) {   // the wave's 64 slots lie in one range: reduce in the wave, one atomic per value
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) v[k] = min(v[k], (unsigned)__shfl_xor((int)v[k], o));
+#pragma unroll
+          for (int k = 3; k < 6; k++) v[k] = max(v[k], (unsigned)__shfl_xor((int)v[k], o));
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) atomicMin(&s_bb[e / W][k], v[k]);
+#pragma unroll
+          for (int k = 3; k < 6; k++) atomicMax(&s_bb[e / W][k], v[k]);
+        }
+      } else if (fin[r]) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) atomicMin(&s_bb[e / W][k], v[k]);
+#pragma unroll
+        for (int k = 3; k < 6; k++) atomicMax(&s_bb[e / W][k], v[k]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kKdPer; r++) {
+      const int e = tid + r * kKdThreads;
+      const int axis = widest_axis(s_bb[e / W]);
+      const float c = axis == 0 ? p[r].x : (axis == 1 ? p[r].y : p[r].z);
+      s_key[e] = fin[r] ? orderable_f32(c) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // bitonic sort of every range of W slots by (key, index).  Slot e = tid + r * kKdThreads lives in register r of thread tid:
+    // partners at distance j >= kKdThreads are registers of the same thread, j < 64 lanes of the same wave (shuffles), only
+    // 64 <= j < kKdThreads goes through LDS behind a barrier (52 barrier stages over all levels instead of 354).
+    unsigned kr[kKdPer];
+    uint32_t ir[kKdPer];
+#pragma unroll
+    for (int r = 0; r < kKdPer; r++) { kr[r] = s_key[tid + r * kKdThreads]; ir[r] = s_idx[tid + r * kKdThreads]; }
+    for (int k = 2; k <= W; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        if (j >= kKdThreads) {
+          const int dr = j / kKdThreads;
+#pragma unroll
+          for (int r = 0; r < kKdPer; r++) {
+            if ((r & dr) == 0) {
+              const int e = tid + r * kKdThreads;
+              const bool up = (k == W) || ((e & k) == 0);
+              const int q = r | dr;
+              const bool a_gt_b = kr[r] > kr[q] || (kr[r] == kr[q] && ir[r] > ir[q]);
+              if (a_gt_b == up) { const unsigned tk = kr[r]; kr[r] = kr[q]; kr[q] = tk; const uint32_t ti = ir[r]; ir[r] = ir[q]; ir[q] = ti; }
+            }
+          }
+        } else {
+          if (j >= kWave) {
+            __syncthreads();   // everybody has read what it needed of the previous exchange
+#pragma unroll
+            for (int r = 0; r < kKdPer; r++) { s_key[tid + r * kKdThreads] = kr[r]; s_idx[tid + r * kKdThreads] = ir[r]; }
+            __syncthreads();
+          }
+#pragma unroll
+          for (int r = 0; r < kKdPer; r++) {
+            const int e = tid + r * kKdThreads;
+            unsigned pk;
+            uint32_t pi;
+            if (j >= kWave) { pk = s_key[e ^ j]; pi = s_idx[e ^ j]; }
+            else { pk = (unsigned)__shfl_xor((int)kr[r], j); pi = (uint32_t)__shfl_xor((int)ir[r], j); }
+            const bool up = (k == W) || ((e & k) == 0);
+            const bool lower = (e & j) == 0;                 // this slot is the lower one of its pair
+            const bool mine_gt = kr[r] > pk || (kr[r] == pk && ir[r] > pi);
+            // the lower slot keeps the smaller key when ascending; the upper slot the larger one
+            const bool take = (lower == up) ? mine_gt : !mine_gt;
+            if (take) { kr[r] = pk; ir[r] = pi; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kKdPer; r++) { s_key[tid + r * kKdThreads] = kr[r]; s_idx[tid + r * kKdThreads] = ir[r]; }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < kKdPer; r++) {
+    const int e = tid + r * kKdThreads;
+    if (e < cnt) vals_out[base + e] = s_idx[e];
   }
 }
 
@@ -190,15 +405,12 @@ __global__ __launch_bounds__(kWave) void nn_fitness_final_kernel(const double* _
 }
 
 // ---- host drivers ----------------------------------------------------------------------------------------------
-int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64, hipStream_t stream) {
+int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64, hipStream_t stream, bool kd_order) {
   hipStream_t st = stream ? stream : h->stream;
   const int n = (int)n64;
   bvh.valid = false;
   bvh.n = n;
   if (n == 0) return DGS_OK;
-  float* d_mm = nullptr;
-  int rc = cloud_minmax_device(h, pts, n, &d_mm, st);
-  if (rc) return rc;
   const int n_leaves = (n + kLeaf - 1) / kLeaf;
   int depth = 1;
   int64_t slots = kFan;
@@ -215,14 +427,50 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64, hipStream
   DGS_HIP_TRY(h, bvh.vals_alt.reserve(n));
   DGS_HIP_TRY(h, bvh.node_lo.reserve((size_t)first_leaf * kFan));
   DGS_HIP_TRY(h, bvh.node_hi.reserve((size_t)first_leaf * kFan));
-  size_t tb = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st);
-  DGS_HIP_TRY(h, h->cub_temp.reserve(tb + 256));
   const int nb = (n + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(hilbert_key_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, d_mm, bvh.keys.ptr, bvh.vals.ptr);
-  tb = h->cub_temp.cap;
-  DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st));
-  hipLaunchKernelGGL(gather_index_kernel, dim3((n_pad + kBlock - 1) / kBlock), dim3(kBlock), 0, st, pts, bvh.vals_alt.ptr, n, n_pad, bvh.sorted.ptr);
+  const uint32_t* order = nullptr;
+  if (kd_order) {
+    // ranges of W slots, W halving; the first W that needs a split is the smallest power of two >= n
+    int64_t W = 16;
+    while (W < n) W <<= 1;
+    const int max_seg = (int)std::max<int64_t>(1, (n + kKdChunk - 1) / kKdChunk);
+    DGS_HIP_TRY(h, bvh.kd_keys.reserve(n));
+    DGS_HIP_TRY(h, bvh.kd_keys_alt.reserve(n));
+    DGS_HIP_TRY(h, bvh.kd_bbox.reserve((size_t)max_seg * 6 + 6));
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.kd_keys.ptr, bvh.kd_keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 64, st);
+    DGS_HIP_TRY(h, h->cub_temp.reserve(tb + 256));
+    uint32_t* va = bvh.vals.ptr;
+    uint32_t* vb = bvh.vals_alt.ptr;
+    hipLaunchKernelGGL(kd_iota_kernel, dim3(nb), dim3(kBlock), 0, st, va, n, bvh.kd_bbox.ptr, 1);
+    for (; W > kKdChunk; W >>= 1) {
+      const int n_seg = (int)((n + W - 1) / W);
+      int seg_bits = 0;
+      while ((1 << seg_bits) < n_seg) seg_bits++;
+      hipLaunchKernelGGL(kd_bbox_kernel, dim3(nb), dim3(kBlock), 0, st, pts, va, n, (int)W, bvh.kd_bbox.ptr);
+      hipLaunchKernelGGL(kd_key_kernel, dim3(nb), dim3(kBlock), 0, st, pts, va, n, (int)W, bvh.kd_bbox.ptr, bvh.kd_keys.ptr);
+      size_t tbytes = h->cub_temp.cap;
+      DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tbytes, bvh.kd_keys.ptr, bvh.kd_keys_alt.ptr, va, vb, n, 0, 32 + seg_bits, st));
+      std::swap(va, vb);
+      const int next_seg = (int)((n + W / 2 - 1) / (W / 2));
+      hipLaunchKernelGGL(kd_clear_bbox_kernel, dim3((next_seg * 6 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, bvh.kd_bbox.ptr, next_seg);
+    }
+    hipLaunchKernelGGL(kd_local_kernel, dim3(max_seg), dim3(kKdThreads), 0, st, pts, va, vb, n);
+    order = vb;
+  } else {
+    float* d_mm = nullptr;
+    int rc = cloud_minmax_device(h, pts, n, &d_mm, st);
+    if (rc) return rc;
+    size_t tb = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st);
+    DGS_HIP_TRY(h, h->cub_temp.reserve(tb + 256));
+    hipLaunchKernelGGL(hilbert_key_kernel, dim3(nb), dim3(kBlock), 0, st, pts, n, d_mm, bvh.keys.ptr, bvh.vals.ptr);
+    tb = h->cub_temp.cap;
+    DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 30, st));
+    order = bvh.vals_alt.ptr;
+  }
+  bvh.kd = kd_order;
+  hipLaunchKernelGGL(gather_index_kernel, dim3((n_pad + kBlock - 1) / kBlock), dim3(kBlock), 0, st, pts, order, n, n_pad, bvh.sorted.ptr);
   // leaf slots first, then every internal level bottom-up (the root's own box is never needed)
   hipLaunchKernelGGL(bvh_boxes_kernel, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, bvh.sorted.ptr, n, first_leaf, (int)slots, 1,
                      first_leaf, bvh.node_lo.ptr, bvh.node_hi.ptr);
@@ -252,13 +500,13 @@ BvhView make_bvh_view(const Bvh& b) {
 static int ensure_target_bvh(dgs_handle* h) {
   if (side_join(h) != DGS_OK) return DGS_ERR_HIP;  // an index being built on the side stream
   if (h->tgt->bvh.valid) return DGS_OK;
-  return bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt);
+  return bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt, nullptr, h->batch_kd || h->nn_kd_all);
 }
 
 // tree + (fitness pass) grid over the current target, on `st` (default: the handle's stream)
 int ensure_target_index(dgs_handle* h, hipStream_t st) {
   int rc = DGS_OK;
-  if (!h->tgt->bvh.valid) rc = bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt, st);
+  if (!h->tgt->bvh.valid) rc = bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt, st, (h->batch_kd || h->nn_kd_all) && !h->use_grid);
   if (rc == DGS_OK && h->use_grid && !h->tgt_grid.valid) rc = nn_grid_build(h, h->tgt_grid, h->tgt->bvh, h->tgt->pts.ptr, h->nt, st);
   return rc;
 }

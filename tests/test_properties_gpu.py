@@ -289,3 +289,101 @@ def test_packed_fp32_derivative_path_matches_the_default(scans):
     rp, rd = p.align_batch(sources[:3], guesses[:3]), d.align_batch(sources[:3], guesses[:3])
     for x, y in zip(rp, rd):
         assert x["converged"] == y["converged"] and abs(x["iterations"] - y["iterations"]) <= 1
+
+
+def _kd_registration(method="NDT_OMP", **kw):
+    """A handle whose target index is always k-d (median split) ordered: the order the loop batch builds on its side stream,
+    reachable here through the single-query hooks (DGS_NN_KD_ALL, read at dgs_create)."""
+    import os
+    from delta_graph_slam_amd.registration import Registration
+    old = os.environ.get("DGS_NN_KD_ALL")
+    os.environ["DGS_NN_KD_ALL"] = "1"
+    try:
+        return Registration(method, **kw)
+    finally:
+        if old is None:
+            del os.environ["DGS_NN_KD_ALL"]
+        else:
+            os.environ["DGS_NN_KD_ALL"] = old
+
+
+def test_kd_ordered_index_is_exact_at_full_size(scans):
+    """The k-d ordered tree (nn_bvh.hip: a global sort per level above 4,096 points, bitonic sorts in LDS below) answers exactly
+    like the Hilbert ordered one: aligned scans, far outliers, shuffled queries, non-finite queries, indices included."""
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, _, gts = scans
+    rng = np.random.default_rng(0)
+    qs = []
+    for s, T in zip(sources[:3], gts[:3]):
+        q = np.ones_like(s)
+        q[:, :3] = f32_transform(T.astype(np.float32), s)
+        qs.append(q)
+    far = np.ones((65536, 4), np.float32)
+    far[:, :3] = rng.uniform(-120, 120, (65536, 3))
+    qs.append(far)
+    qs.append(qs[0][rng.permutation(65536)])
+    q = np.concatenate(qs, 0)
+    q[5, 0] = np.nan
+    q[9, 2] = np.inf
+    h = Registration("NDT_OMP")
+    h.setInputTarget(tgt)
+    k = _kd_registration()
+    k.setInputTarget(tgt)
+    ih, dh = h.nearestKSearch(q)
+    ik, dk = k.nearestKSearch(q)
+    assert np.array_equal(dh, dk, equal_nan=True)
+    assert np.array_equal(ih, ik)            # ties -> lowest index in both
+
+
+@pytest.mark.parametrize("n", [1, 5, 8, 9, 63, 64, 65, 511, 513, 4095, 4096, 4097, 8191, 8193, 20000, 70001, 200000])
+def test_kd_ordered_index_on_every_size_class(n):
+    """Sizes around the leaf (8), the LDS chunk (4,096) and the global levels; targets with duplicates and non-finite points."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(n)
+    tgt = np.ones((n, 4), np.float32)
+    tgt[:, :3] = rng.normal(0, 4, (n, 3)) * [1, 1, 0.05]
+    if n > 64:
+        tgt[rng.choice(n, n // 50, replace=False), :3] = tgt[0, :3]      # duplicates
+        tgt[rng.choice(np.arange(1, n), 3, replace=False), 1] = np.nan     # non-finite points never win
+    q = np.ones((3000, 4), np.float32)
+    q[:, :3] = rng.normal(0, 5, (3000, 3)) * [1, 1, 0.1]
+    k = _kd_registration()
+    k.setInputTarget(tgt)
+    idx, sq = k.nearestKSearch(q)
+    ok = np.isfinite(tgt[:, :3]).all(1)
+    ref = np.flatnonzero(ok)
+    _, nn = cKDTree(tgt[ok, :3].astype(np.float64)).query(q[:, :3].astype(np.float64), k=1)
+    want = f32_sqdist(q[:, :3], tgt[ref[nn], :3])
+    assert np.array_equal(sq, f32_sqdist(q[:, :3], tgt[idx, :3]))
+    assert np.all(sq <= want) and np.all(sq >= want * (1 - 1e-5))
+    # lowest index among the points at the winning distance
+    d_all = None
+    if n <= 9000:
+        d_all = ((q[:200, None, :3].astype(np.float32) - tgt[None, :, :3]) ** 2)
+        d_all = (d_all[..., 0] + d_all[..., 1]) + d_all[..., 2]
+        d_all[:, ~ok] = np.inf
+        assert np.array_equal(idx[:200], np.argmin(d_all, axis=1))
+
+
+def test_loop_batch_uses_the_kd_order_and_scores_like_the_hilbert_order(scans):
+    """dgs_align_batch builds the target's index k-d ordered on its side stream (DGS_NN_KD=0: Hilbert ordered): the candidates'
+    fitness scores are sums of the same float distances, so they agree to the order of the double sums."""
+    import os
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, _ = scans
+    out = {}
+    for kd in ("1", "0"):
+        old = os.environ.get("DGS_NN_KD")
+        os.environ["DGS_NN_KD"] = kd
+        try:
+            r = Registration("NDT_OMP", ndt_resolution=1.0)
+        finally:
+            if old is None:
+                del os.environ["DGS_NN_KD"]
+            else:
+                os.environ["DGS_NN_KD"] = old
+        r.setInputTarget(tgt)
+        out[kd] = r.align_batch(sources, guesses)
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a["T"], b["T"]) and a["converged"] == b["converged"]
+        assert abs(a["fitness"] - b["fitness"]) <= 1e-12 * abs(b["fitness"])
