@@ -527,6 +527,8 @@ int dgs_nn_fitness_distances(dgs_handle* h, const float* queries, int64_t m, int
 // FAST_GICP over a batch of sources (loop_detector.hpp:137-156): batched align, then one fitness launch for all candidates
 static int gicp_batch(dgs_handle* h, int n, CloudState* const* cs, const float* guesses16, int compute_fitness, double fitness_max_range,
                       dgs_result* results) {
+  struct KdScope { dgs_handle* h; ~KdScope() { h->batch_kd = false; } } kd_scope{h};
+  h->batch_kd = h->nn_kd && n >= 4;   // an index built for the target of this batch is k-d ordered
   int rc = gicp_align_batch(h, n, cs, guesses16, results);
   if (rc == DGS_OK && compute_fitness) {
     DGS_HIP_TRY(h, h->src_ptrs.reserve(n));

@@ -874,7 +874,8 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
     return DGS_ERR_UNSUPPORTED;
   }
   if (!c.bvh.valid) {
-    int rc = bvh_build(h, c.bvh, c.pts.ptr, c.n);
+    // the target of a batch is searched by every candidate at every linearisation: worth the slower k-d ordered build (nn_bvh.hip)
+    int rc = bvh_build(h, c.bvh, c.pts.ptr, c.n, nullptr, h->batch_kd && &c == h->tgt);
     if (rc) return rc;
   }
   DGS_HIP_TRY(h, c.cov.reserve((size_t)c.n * 6));
