@@ -1295,8 +1295,8 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   long queued = 0;
   const bool fused = h->ndt_fused && h->consts.strict_order == DGS_NDT_ORDER_FAST;
   int launch_no = 0;
-  auto enqueue_chunk = [&](int slot) -> int {
-    for (int e = 0; e < chunk; e++) {
+  auto enqueue_chunk = [&](int slot, int launches) -> int {
+    for (int e = 0; e < launches; e++) {
       if (fused) {
         launch_derivatives(h, L, launch_no++);
       } else {
@@ -1304,18 +1304,22 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
         launch_solve(h, L);
       }
     }
-    queued += chunk;
+    queued += launches;
     DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
     DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
     return DGS_OK;
   };
   int cur = 0;
-  rc = enqueue_chunk(0);
+  // with a build waiting for the side stream the first chunk is twice as long: the host needs ~0.1 ms to enqueue that build, and
+  // the main stream must not run dry meanwhile.  (Also tried: the fused launches writing the count of finished pairs into pinned
+  // host memory themselves instead of a copy command per chunk -- the one more kernel argument pushed the derivative loop over its
+  // 128 VGPRs (4 spilled registers, 34 -> 40 us per launch): the copies stay.)
+  rc = enqueue_chunk(0, h->side_build_deferred ? 2 * chunk : chunk);
   bool finished = false;
   bool first = true;
   while (rc == DGS_OK) {
     const bool more = queued < max_evals;
-    if (more) rc = enqueue_chunk(cur ^ 1);
+    if (more) rc = enqueue_chunk(cur ^ 1, chunk);
     if (rc != DGS_OK) break;
     // two chunks are in flight: now the host has time to enqueue what dgs_align_batch left for the side stream
     if (first && (rc = side_build_now(h)) != DGS_OK) break;
