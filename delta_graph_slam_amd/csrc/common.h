@@ -105,6 +105,8 @@ struct GicpPair {
   int active;
   GicpSolver s;
   float final_T[16];  // column-major
+  int last_launch;    // fused rounds: the pair takes part in the linearize launches numbered <= last_launch (written by its closing workgroup)
+  int ticket;         // fused rounds: workgroups of this pair that have published their row in the running launch
 };
 
 // ---- FAST_VGICP target model: GaussianVoxelMap (ADDITIVE) ----------------------------------------------------------------

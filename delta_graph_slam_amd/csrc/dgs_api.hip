@@ -228,6 +228,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (const char* e = std::getenv("DGS_KNN_LEAF")) h->knn_leaf = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_KNN_MIN_WAVES")) h->knn_min_waves = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DGS_KNN_ROUNDS")) h->knn_rounds = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("DGS_GICP_FUSED")) h->gicp_fused = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NDT_PACK2")) h->ndt_pack2 = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_GRID_FACTOR")) h->grid_spacing_factor = std::max(0.5f, (float)std::atof(e));
   std::memset(h->final_T, 0, sizeof(h->final_T));

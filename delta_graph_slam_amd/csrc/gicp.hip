@@ -485,6 +485,7 @@ __device__ __forceinline__ void gicp_mahalanobis(const double* T, const double* 
 }
 
 // wave DPP sums -> LDS -> one fixed-order row of kAccumPad doubles per workgroup
+template <bool FUSED = false>
 __device__ __forceinline__ void gicp_block_reduce(const double* acc, double* __restrict__ row) {
   __shared__ double sm[kBlock / kWave][kAccumPad];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -497,17 +498,254 @@ __device__ __forceinline__ void gicp_block_reduce(const double* acc, double* __r
   if (threadIdx.x < kAccumPad) {
     double v = 0.0;
     if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    row[threadIdx.x] = v;
+    if (FUSED) {
+      __hip_atomic_store(row + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: see gicp_close_round
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      row[threadIdx.x] = v;
+    }
   }
 }
 
+// ---- the optimiser (forced inline: inside the fused linearize kernels the launch bound of the linearize loop must govern, the
+// tail spills what does not fit)
+// ================================================================================================ solver
+// so3_exp / se3_exp of fast_gicp (quaternion form); out = rows 0..2 of the 4x4, row-major 3x4
+__device__ __forceinline__ void se3_exp_dev(const double* a, double* T) {
+  const double wx = a[0], wy = a[1], wz = a[2];
+  const double theta_sq = wx * wx + wy * wy + wz * wz;
+  double imag, real;
+  if (theta_sq < 1e-10) {
+    const double tq = theta_sq * theta_sq;
+    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
+    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
+  } else {
+    const double theta = sqrt(theta_sq), half = 0.5 * theta;
+    imag = sin(half) / theta;
+    real = cos(half);
+  }
+  const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
+  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+  const double theta = sqrt(theta_sq);
+  double V[9];
+  if (theta < 1e-10) {
+    for (int i = 0; i < 9; i++) V[i] = R[i];
+  } else {
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3 + 0] * O[0 * 3 + c] + O[r * 3 + 1] * O[1 * 3 + c] + O[r * 3 + 2] * O[2 * 3 + c];
+    const double c1 = (1.0 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+  }
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) T[r * 4 + c] = R[r * 3 + c];
+    T[r * 4 + 3] = V[r * 3 + 0] * a[3] + V[r * 3 + 1] * a[4] + V[r * 3 + 2] * a[5];
+  }
+}
+
+__device__ __forceinline__ void iso_mul(const double* A, const double* B, double* C) {  // 3x4 isometries, C = A * B
+  double T[12];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 4; c++) T[r * 4 + c] = A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c] + A[r * 4 + 2] * B[2 * 4 + c];
+    T[r * 4 + 3] += A[r * 4 + 3];
+  }
+  for (int k = 0; k < 12; k++) C[k] = T[k];
+}
+
+__device__ __forceinline__ bool gicp_is_converged(const double* delta, const GicpConsts& c) {
+  double rmax = 0, tmax = 0;
+  for (int r = 0; r < 3; r++) {
+    for (int cc = 0; cc < 3; cc++) rmax = fmax(rmax, fabs(delta[r * 4 + cc] - (r == cc ? 1.0 : 0.0)) / c.rot_eps);
+    tmax = fmax(tmax, fabs(delta[r * 4 + 3]) / c.trans_eps);
+  }
+  return fmax(rmax, tmax) < 1;
+}
+
+__device__ __forceinline__ void gicp_queue(GicpPair* st, const double* T, int kind, bool writer) {
+  if (writer) {
+    for (int k = 0; k < 12; k++) st->Teval[k] = T[k];
+    st->eval_kind = kind;
+  }
+}
+
+__device__ __forceinline__ void gicp_try_lm(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
+  double Hl[36], nb[6];
+  for (int k = 0; k < 36; k++) Hl[k] = s.H[k];
+  for (int k = 0; k < 6; k++) { Hl[k * 6 + k] += s.lambda; nb[k] = -s.b[k]; }
+  solve6_wave(Hl, nb, s.d);
+  se3_exp_dev(s.d, s.delta);
+  iso_mul(s.delta, s.x0, s.xi);
+  gicp_queue(st, s.xi, 1, writer);
+  s.phase = GP_ERROR_WAIT;
+}
+
+// after a successful optimisation step: convergence test of LsqRegistration::computeTransformation
+__device__ __forceinline__ void gicp_after_step(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
+  const bool conv = gicp_is_converged(s.delta, c);
+  s.converged = conv ? 1 : 0;
+  if (!conv && s.iteration + 1 < c.max_iterations) {
+    s.iteration++;
+    gicp_queue(st, s.x0, 0, writer);
+    s.phase = GP_LINEARIZE_WAIT;
+  } else {
+    s.phase = GP_DONE;
+  }
+}
+
+__device__ __forceinline__ void gicp_advance(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
+  s.evaluations++;
+  if (s.phase == GP_PROBE) {
+    s.phase = GP_DONE;
+    return;
+  }
+  if (s.phase == GP_LINEARIZE_WAIT) {
+    if (c.optimizer == DGS_GICP_OPT_GAUSS_NEWTON) {
+      double nb[6];
+      for (int k = 0; k < 6; k++) nb[k] = -s.b[k];
+      solve6_wave(s.H, nb, s.d);
+      se3_exp_dev(s.d, s.delta);
+      iso_mul(s.delta, s.x0, s.x0);
+      gicp_after_step(st, s, c, writer);
+      return;
+    }
+    if (s.lambda < 0.0) {
+      double m = 0;
+      for (int k = 0; k < 6; k++) m = fmax(m, fabs(s.H[k * 6 + k]));
+      s.lambda = c.lm_init_lambda_factor * m;
+    }
+    s.nu = 2.0;
+    s.lm_try = 0;
+    gicp_try_lm(st, s, c, writer);
+    return;
+  }
+  if (s.phase == GP_ERROR_WAIT) {
+    double denom = 0;
+    for (int k = 0; k < 6; k++) denom += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
+    const double rho = (s.y0 - s.yi) / denom;
+    if (rho < 0) {
+      if (gicp_is_converged(s.delta, c)) {  // step_lm returns true without moving x0
+        gicp_after_step(st, s, c, writer);
+        return;
+      }
+      s.lambda = s.nu * s.lambda;
+      s.nu = 2 * s.nu;
+      s.lm_try++;
+      if (s.lm_try < c.lm_max_iterations) {
+        gicp_try_lm(st, s, c, writer);
+      } else {  // "lm not converged!!": the outer loop breaks, converged_ stays false
+        s.converged = 0;
+        s.phase = GP_DONE;
+      }
+      return;
+    }
+    for (int k = 0; k < 12; k++) s.x0[k] = s.xi[k];
+    const double t = 2 * rho - 1;
+    s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
+    s.y0 = s.yi;
+    gicp_after_step(st, s, c, writer);
+  }
+}
+
+// The optimiser step of a registration from its partial rows: gicp_solve_kernel's body, also run by the LAST workgroup of a
+// pair inside the linearize launch (fused rounds).  Rows are summed in the same order either way (bit-identical results).
+template <bool FUSED>
+__device__ __forceinline__ void gicp_step_from_rows(GicpPair* st, const double* __restrict__ partials, const int nblocks, const GicpConsts& c,
+                                                    int* __restrict__ done_counter, const int launch) {
+  __shared__ double sm[kBlock / kAccumPad][kAccumPad];
+  __shared__ double tot[kAccumPad];
+  __shared__ GicpSolver s_lds;   // the state lives in LDS: in registers it would cost the linearize loop half its occupancy
+  const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
+  constexpr int G = kBlock / kAccumPad;
+  double v = 0.0;
+  for (int b = grp; b < nblocks; b += G) {
+    const double* r = partials + (size_t)b * kAccumPad + col;
+    v += FUSED ? __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *r;
+  }
+  sm[grp][col] = v;
+  {  // state -> LDS, word by word, by the whole workgroup
+    const int* src = reinterpret_cast<const int*>(&st->s);
+    int* dst = reinterpret_cast<int*>(&s_lds);
+    for (int w = threadIdx.x; w < (int)(sizeof(GicpSolver) / sizeof(int)); w += kBlock) dst[w] = src[w];
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumPad) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  const bool writer = threadIdx.x == 0;
+  GicpSolver& s = s_lds;
+  if (st->eval_kind == 0) {
+    if (writer) {
+      s.y0 = tot[0];
+      for (int k = 0; k < 6; k++) s.b[k] = tot[1 + k];
+      int q = 7;
+      for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) {
+          s.H[i * 6 + j] = tot[q];
+          s.H[j * 6 + i] = tot[q];
+          q++;
+        }
+    }
+  } else if (writer) {
+    s.yi = tot[0];
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  gicp_advance(st, s, c, writer);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  {
+    const int* src = reinterpret_cast<const int*>(&s_lds);
+    int* dst = reinterpret_cast<int*>(&st->s);
+    for (int w = threadIdx.x; w < (int)(sizeof(GicpSolver) / sizeof(int)); w += kWave) dst[w] = src[w];
+  }
+  if (writer) {
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < 4; cc++) st->final_T[cc * 4 + r] = (float)s.x0[r * 4 + cc];
+    st->final_T[3] = st->final_T[7] = st->final_T[11] = 0.f;
+    st->final_T[15] = 1.f;
+    if (s.phase == GP_DONE) {
+      st->active = 0;
+      if (FUSED) st->last_launch = launch;
+      atomicAdd(done_counter, 1);
+    }
+  }
+}
+
+// Fused rounds: after its row is published (write-through stores, drained) a workgroup takes a ticket of its pair; the one that
+// takes the last ticket runs the pair's optimiser step -- the scheme of ndt_derivatives_kernel<.., fused> (ndt_align.hip).
+__device__ __forceinline__ void gicp_close_round(GicpPair* pairs, const int pair, const int nblocks, const double* __restrict__ partials_of_pair,
+                                                 const GicpConsts& c, int* __restrict__ done_counter, const int launch) {
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(&pairs[pair].ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == nblocks - 1) ? 1 : 0;
+    if (last) pairs[pair].ticket = 0;
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  gicp_step_from_rows<true>(pairs + pair, partials_of_pair, nblocks, c, done_counter, launch);
+}
+
 // ================================================================================================ K6 linearize / error
-__global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const GicpItem* __restrict__ items, const float4* __restrict__ tgt,
-                                                                const double* __restrict__ cov_t, const GicpPair* __restrict__ pairs,
+// fused: the linearize loop keeps its 4 waves per SIMD; the optimiser tail (one workgroup per pair and launch) spills what does not fit
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock, FUSED ? 4 : 1) void gicp_linearize_kernel(const GicpItem* __restrict__ items, const float4* __restrict__ tgt,
+                                                                const double* __restrict__ cov_t, GicpPair* __restrict__ pairs,
                                                                 double* __restrict__ partials, const int n_pairs, const int cap_blocks,
-                                                                int* __restrict__ pair_blocks) {
+                                                                int* __restrict__ pair_blocks, const GicpConsts consts, int* __restrict__ done_counter,
+                                                                const int launch) {
   int pair, slice, nblocks;
-  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, nblocks)) return;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return FUSED ? (launch <= pairs[pi].last_launch) : (pairs[pi].active != 0); }, pair, slice, nblocks)) return;
   if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = nblocks;
   const GicpPair& st = pairs[pair];
   const GicpItem it = items[pair];
@@ -545,7 +783,8 @@ __global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const GicpItem* 
     const double t2 = T[8] * ax + T[9] * ay + T[10] * az + T[11];
     gicp_accumulate<false>(acc, M, (double)pb.x - t0, (double)pb.y - t1, (double)pb.z - t2, t0, t1, t2, 1.0, full);
   }
-  gicp_block_reduce(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
+  gicp_block_reduce<FUSED>(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
+  if (FUSED) gicp_close_round(pairs, pair, nblocks, partials + (size_t)pair * cap_blocks * kAccumPad, consts, done_counter, launch);
 }
 
 // ================================================================================================ FAST_VGICP linearize / error
@@ -553,11 +792,13 @@ __global__ __launch_bounds__(kBlock) void gicp_linearize_kernel(const GicpItem* 
 // (double) and its DIRECT1 / 7 / 27 neighbours are looked up in the dense cell table -- no tree, no distance gate --, every hit is
 // a correspondence with Mahalanobis (cov_voxel + R cov_p R^T)^-1 and weight sqrt(points in the voxel).  An error-only
 // evaluation re-uses the voxel ids and Mahalanobis matrices stored by the last linearisation, as upstream does.
-__global__ __launch_bounds__(kBlock) void vgicp_linearize_kernel(const GicpItem* __restrict__ items, const VgicpMap m,
-                                                                 const GicpPair* __restrict__ pairs, double* __restrict__ partials,
-                                                                 const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks) {
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock, FUSED ? 3 : 1) void vgicp_linearize_kernel(const GicpItem* __restrict__ items, const VgicpMap m,
+                                                                 GicpPair* __restrict__ pairs, double* __restrict__ partials,
+                                                                 const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks,
+                                                                 const GicpConsts consts, int* __restrict__ done_counter, const int launch) {
   int pair, slice, nblocks;
-  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, nblocks)) return;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return FUSED ? (launch <= pairs[pi].last_launch) : (pairs[pi].active != 0); }, pair, slice, nblocks)) return;
   if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = nblocks;
   const GicpPair& st = pairs[pair];
   const GicpItem it = items[pair];
@@ -615,199 +856,17 @@ __global__ __launch_bounds__(kBlock) void vgicp_linearize_kernel(const GicpItem*
       gicp_accumulate<true>(acc, M, vx->mean[0] - t0, vx->mean[1] - t1, vx->mean[2] - t2, t0, t1, t2, vx->w, full);
     }
   }
-  gicp_block_reduce(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
+  gicp_block_reduce<FUSED>(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
+  if (FUSED) gicp_close_round(pairs, pair, nblocks, partials + (size_t)pair * cap_blocks * kAccumPad, consts, done_counter, launch);
 }
 
-// ================================================================================================ solver
-// so3_exp / se3_exp of fast_gicp (quaternion form); out = rows 0..2 of the 4x4, row-major 3x4
-__device__ void se3_exp_dev(const double* a, double* T) {
-  const double wx = a[0], wy = a[1], wz = a[2];
-  const double theta_sq = wx * wx + wy * wy + wz * wz;
-  double imag, real;
-  if (theta_sq < 1e-10) {
-    const double tq = theta_sq * theta_sq;
-    imag = 0.5 - 1.0 / 48.0 * theta_sq + 1.0 / 3840.0 * tq;
-    real = 1.0 - 1.0 / 8.0 * theta_sq + 1.0 / 384.0 * tq;
-  } else {
-    const double theta = sqrt(theta_sq), half = 0.5 * theta;
-    imag = sin(half) / theta;
-    real = cos(half);
-  }
-  const double qw = real, qx = imag * wx, qy = imag * wy, qz = imag * wz;
-  const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
-  const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
-  const double theta = sqrt(theta_sq);
-  double V[9];
-  if (theta < 1e-10) {
-    for (int i = 0; i < 9; i++) V[i] = R[i];
-  } else {
-    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-    double O2[9];
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) O2[r * 3 + c] = O[r * 3 + 0] * O[0 * 3 + c] + O[r * 3 + 1] * O[1 * 3 + c] + O[r * 3 + 2] * O[2 * 3 + c];
-    const double c1 = (1.0 - cos(theta)) / theta_sq, c2 = (theta - sin(theta)) / (theta_sq * theta);
-    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
-  }
-  for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 3; c++) T[r * 4 + c] = R[r * 3 + c];
-    T[r * 4 + 3] = V[r * 3 + 0] * a[3] + V[r * 3 + 1] * a[4] + V[r * 3 + 2] * a[5];
-  }
-}
-
-__device__ inline void iso_mul(const double* A, const double* B, double* C) {  // 3x4 isometries, C = A * B
-  double T[12];
-  for (int r = 0; r < 3; r++) {
-    for (int c = 0; c < 4; c++) T[r * 4 + c] = A[r * 4 + 0] * B[0 * 4 + c] + A[r * 4 + 1] * B[1 * 4 + c] + A[r * 4 + 2] * B[2 * 4 + c];
-    T[r * 4 + 3] += A[r * 4 + 3];
-  }
-  for (int k = 0; k < 12; k++) C[k] = T[k];
-}
-
-__device__ inline bool gicp_is_converged(const double* delta, const GicpConsts& c) {
-  double rmax = 0, tmax = 0;
-  for (int r = 0; r < 3; r++) {
-    for (int cc = 0; cc < 3; cc++) rmax = fmax(rmax, fabs(delta[r * 4 + cc] - (r == cc ? 1.0 : 0.0)) / c.rot_eps);
-    tmax = fmax(tmax, fabs(delta[r * 4 + 3]) / c.trans_eps);
-  }
-  return fmax(rmax, tmax) < 1;
-}
-
-__device__ void gicp_queue(GicpPair* st, const double* T, int kind, bool writer) {
-  if (writer) {
-    for (int k = 0; k < 12; k++) st->Teval[k] = T[k];
-    st->eval_kind = kind;
-  }
-}
-
-__device__ void gicp_try_lm(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
-  double Hl[36], nb[6];
-  for (int k = 0; k < 36; k++) Hl[k] = s.H[k];
-  for (int k = 0; k < 6; k++) { Hl[k * 6 + k] += s.lambda; nb[k] = -s.b[k]; }
-  solve6_wave(Hl, nb, s.d);
-  se3_exp_dev(s.d, s.delta);
-  iso_mul(s.delta, s.x0, s.xi);
-  gicp_queue(st, s.xi, 1, writer);
-  s.phase = GP_ERROR_WAIT;
-}
-
-// after a successful optimisation step: convergence test of LsqRegistration::computeTransformation
-__device__ void gicp_after_step(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
-  const bool conv = gicp_is_converged(s.delta, c);
-  s.converged = conv ? 1 : 0;
-  if (!conv && s.iteration + 1 < c.max_iterations) {
-    s.iteration++;
-    gicp_queue(st, s.x0, 0, writer);
-    s.phase = GP_LINEARIZE_WAIT;
-  } else {
-    s.phase = GP_DONE;
-  }
-}
-
-__device__ void gicp_advance(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
-  s.evaluations++;
-  if (s.phase == GP_PROBE) {
-    s.phase = GP_DONE;
-    return;
-  }
-  if (s.phase == GP_LINEARIZE_WAIT) {
-    if (c.optimizer == DGS_GICP_OPT_GAUSS_NEWTON) {
-      double nb[6];
-      for (int k = 0; k < 6; k++) nb[k] = -s.b[k];
-      solve6_wave(s.H, nb, s.d);
-      se3_exp_dev(s.d, s.delta);
-      iso_mul(s.delta, s.x0, s.x0);
-      gicp_after_step(st, s, c, writer);
-      return;
-    }
-    if (s.lambda < 0.0) {
-      double m = 0;
-      for (int k = 0; k < 6; k++) m = fmax(m, fabs(s.H[k * 6 + k]));
-      s.lambda = c.lm_init_lambda_factor * m;
-    }
-    s.nu = 2.0;
-    s.lm_try = 0;
-    gicp_try_lm(st, s, c, writer);
-    return;
-  }
-  if (s.phase == GP_ERROR_WAIT) {
-    double denom = 0;
-    for (int k = 0; k < 6; k++) denom += s.d[k] * (s.lambda * s.d[k] - s.b[k]);
-    const double rho = (s.y0 - s.yi) / denom;
-    if (rho < 0) {
-      if (gicp_is_converged(s.delta, c)) {  // step_lm returns true without moving x0
-        gicp_after_step(st, s, c, writer);
-        return;
-      }
-      s.lambda = s.nu * s.lambda;
-      s.nu = 2 * s.nu;
-      s.lm_try++;
-      if (s.lm_try < c.lm_max_iterations) {
-        gicp_try_lm(st, s, c, writer);
-      } else {  // "lm not converged!!": the outer loop breaks, converged_ stays false
-        s.converged = 0;
-        s.phase = GP_DONE;
-      }
-      return;
-    }
-    for (int k = 0; k < 12; k++) s.x0[k] = s.xi[k];
-    const double t = 2 * rho - 1;
-    s.lambda = s.lambda * fmax(1.0 / 3.0, 1 - t * t * t);
-    s.y0 = s.yi;
-    gicp_after_step(st, s, c, writer);
-  }
-}
 
 __global__ __launch_bounds__(kBlock) void gicp_solve_kernel(GicpPair* __restrict__ pairs, const double* __restrict__ all_partials,
                                                             const int* __restrict__ pair_blocks, const int cap_blocks, const GicpConsts c,
                                                             int* __restrict__ done_counter) {
   GicpPair* st = pairs + blockIdx.x;  // one workgroup per registration of the batch
   if (!st->active) return;
-  const int nblocks = pair_blocks[blockIdx.x];
-  const double* __restrict__ partials = all_partials + (size_t)blockIdx.x * cap_blocks * kAccumPad;
-  __shared__ double sm[kBlock / kAccumPad][kAccumPad];
-  const int col = threadIdx.x % kAccumPad, grp = threadIdx.x / kAccumPad;
-  constexpr int G = kBlock / kAccumPad;
-  double v = 0.0;
-  for (int b = grp; b < nblocks; b += G) v += partials[(size_t)b * kAccumPad + col];
-  sm[grp][col] = v;
-  __syncthreads();
-  __shared__ double tot[kAccumPad];
-  if (threadIdx.x < kAccumPad) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
-    tot[threadIdx.x] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x >= kWave) return;
-  const bool writer = threadIdx.x == 0;
-  GicpSolver s = st->s;
-  if (st->eval_kind == 0) {
-    s.y0 = tot[0];
-    for (int k = 0; k < 6; k++) s.b[k] = tot[1 + k];
-    int q = 7;
-    for (int i = 0; i < 6; i++)
-      for (int j = i; j < 6; j++) {
-        s.H[i * 6 + j] = tot[q];
-        s.H[j * 6 + i] = tot[q];
-        q++;
-      }
-  } else {
-    s.yi = tot[0];
-  }
-  gicp_advance(st, s, c, writer);
-  if (writer) {
-    st->s = s;
-    for (int r = 0; r < 3; r++)
-      for (int cc = 0; cc < 4; cc++) st->final_T[cc * 4 + r] = (float)s.x0[r * 4 + cc];
-    st->final_T[3] = st->final_T[7] = st->final_T[11] = 0.f;
-    st->final_T[15] = 1.f;
-    if (s.phase == GP_DONE) {
-      st->active = 0;
-      atomicAdd(done_counter, 1);
-    }
-  }
+  gicp_step_from_rows<false>(st, all_partials + (size_t)blockIdx.x * cap_blocks * kAccumPad, pair_blocks[blockIdx.x], c, done_counter, -1);
 }
 
 struct GicpInit {
@@ -837,6 +896,8 @@ __global__ void gicp_init_kernel(GicpPair* __restrict__ pairs, const GicpInit* _
   st->s = s;
   st->eval_kind = (init->probe_kind > 0) ? 1 : 0;
   st->active = (init->n > 0) ? 1 : 0;
+  st->last_launch = (init->n > 0) ? 0x7FFFFFFF : -1;
+  st->ticket = 0;
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 4; c++) st->final_T[c * 4 + r] = (float)init->x0[r * 4 + c];
   st->final_T[3] = st->final_T[7] = st->final_T[11] = 0.f;
@@ -935,14 +996,22 @@ static GicpLaunch gicp_choose_launch(int n_pairs, int64_t max_n) {
   return L;
 }
 
-static void gicp_launch_round(dgs_handle* h, const GicpLaunch& L) {
+static void gicp_launch_round(dgs_handle* h, const GicpLaunch& L, const int launch) {
+  // fused rounds (default; DGS_GICP_FUSED=0 restores the separate solve launch): the optimiser step of a pair runs in the last
+  // workgroup of its linearize slice -- two dependent launches per evaluation instead of three (VGICP: one instead of two)
+  const bool fused = h->gicp_fused;
   if (h->prm.method == DGS_METHOD_VGICP) {
     int slot = prof_begin(h, DGS_K_GICP_LINEARIZE);
-    hipLaunchKernelGGL(vgicp_linearize_kernel, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->vmap, h->gpairs.ptr, h->partials.ptr,
-                       L.n_pairs, L.cap_l, h->pair_blocks.ptr);
+    if (fused)
+      hipLaunchKernelGGL(vgicp_linearize_kernel<true>, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->vmap, h->gpairs.ptr, h->partials.ptr,
+                         L.n_pairs, L.cap_l, h->pair_blocks.ptr, h->gconsts, h->done_counter.ptr, launch);
+    else
+      hipLaunchKernelGGL(vgicp_linearize_kernel<false>, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->vmap, h->gpairs.ptr, h->partials.ptr,
+                         L.n_pairs, L.cap_l, h->pair_blocks.ptr, h->gconsts, h->done_counter.ptr, launch);
     prof_end(h, DGS_K_GICP_LINEARIZE, slot);
-    hipLaunchKernelGGL(gicp_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, h->pair_blocks.ptr, L.cap_l,
-                       h->gconsts, h->done_counter.ptr);
+    if (!fused)
+      hipLaunchKernelGGL(gicp_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, h->pair_blocks.ptr, L.cap_l,
+                         h->gconsts, h->done_counter.ptr);
     return;
   }
   const BvhView v = make_bvh_view(h->tgt->bvh);
@@ -951,11 +1020,16 @@ static void gicp_launch_round(dgs_handle* h, const GicpLaunch& L) {
                      h->gconsts.max_corr_sq);
   prof_end(h, DGS_K_NN_SEARCH, slot);
   slot = prof_begin(h, DGS_K_GICP_LINEARIZE);
-  hipLaunchKernelGGL(gicp_linearize_kernel, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->tgt->pts.ptr, h->tgt->cov.ptr, h->gpairs.ptr,
-                     h->partials.ptr, L.n_pairs, L.cap_l, h->pair_blocks.ptr);
+  if (fused)
+    hipLaunchKernelGGL(gicp_linearize_kernel<true>, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->tgt->pts.ptr, h->tgt->cov.ptr, h->gpairs.ptr,
+                       h->partials.ptr, L.n_pairs, L.cap_l, h->pair_blocks.ptr, h->gconsts, h->done_counter.ptr, launch);
+  else
+    hipLaunchKernelGGL(gicp_linearize_kernel<false>, dim3(L.grid_l), dim3(kBlock), 0, h->stream, h->gitems.ptr, h->tgt->pts.ptr, h->tgt->cov.ptr, h->gpairs.ptr,
+                       h->partials.ptr, L.n_pairs, L.cap_l, h->pair_blocks.ptr, h->gconsts, h->done_counter.ptr, launch);
   prof_end(h, DGS_K_GICP_LINEARIZE, slot);
-  hipLaunchKernelGGL(gicp_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, h->pair_blocks.ptr, L.cap_l,
-                     h->gconsts, h->done_counter.ptr);
+  if (!fused)
+    hipLaunchKernelGGL(gicp_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->gpairs.ptr, h->partials.ptr, h->pair_blocks.ptr, L.cap_l,
+                       h->gconsts, h->done_counter.ptr);
 }
 
 // pinned staging: [0,64) done flags | inits | items | pairs read back
@@ -1073,8 +1147,9 @@ int gicp_align_batch(dgs_handle* h, int n, CloudState* const* srcs, const float*
     const long max_rounds = (long)h->prm.maximum_iterations * (h->prm.gicp_lm_max_iterations + 1) + 4;
     const int chunk = 4;
     long queued = 0;
+    int launch_no = 0;
     auto enqueue_chunk = [&](int slot) -> int {
-      for (int e = 0; e < chunk; e++) gicp_launch_round(h, L);
+      for (int e = 0; e < chunk; e++) gicp_launch_round(h, L, launch_no++);
       queued += chunk;
       DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
       DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
@@ -1147,7 +1222,7 @@ int gicp_probe(dgs_handle* h, const double* T16, int error_only, double* err, do
   int rc = gicp_start(h, 1, one, T16, error_only ? 1 : 0, &L, &n_live);
   if (rc) return rc;
   if (n_live == 0) return DGS_ERR_NO_SOURCE;
-  gicp_launch_round(h, L);
+  gicp_launch_round(h, L, 0);
   GicpPair* hp = gicp_read_back(h, 1, &rc);
   if (rc) return rc;
   *err = error_only ? hp->s.yi : hp->s.y0;

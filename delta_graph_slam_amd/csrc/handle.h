@@ -164,6 +164,7 @@ struct dgs_handle {
   bool knn_leaf = true;               // DGS_KNN_LEAF=0: the per-query k-NN walk (gicp_knn_kernel) instead of the wave-per-leaf search
   int knn_min_waves = 4096;           // DGS_KNN_MIN_WAVES: ... but never fewer waves than this (4 per SIMD)
   int knn_rounds = 8;                 // DGS_KNN_ROUNDS: rounds of 8 adjacent queries per wave in gicp_knn_kernel (1 = no warm bounds)
+  bool gicp_fused = true;             // DGS_GICP_FUSED=0: the optimiser step of FAST_GICP / FAST_VGICP as its own launch (gicp_solve_kernel)
   bool ndt_pack2 = false;             // DGS_NDT_PACK2=1: DIRECT7 derivatives with two points per lane on packed FP32 (A/B measurements)
   bool ndt_fused = true;              // DGS_NDT_FUSED=0 at dgs_create: (derivatives, solve) launch pairs instead of fused launches
 

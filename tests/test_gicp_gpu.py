@@ -228,3 +228,32 @@ def test_wave_per_leaf_knn_finds_the_sets_of_the_per_query_walk():
         scale = np.maximum(np.abs(b[finite]).max(axis=(1, 2)), 1e-300)
         err = np.abs(a[finite] - b[finite]).max(axis=(1, 2)) / scale
         assert err.max() < 1e-11, (name, float(err.max()), int((err > 1e-11).sum()))
+
+
+@pytest.mark.parametrize("method", ["FAST_GICP", "FAST_VGICP"])
+def test_fused_rounds_equal_separate_solve_launches_bit_for_bit(method):
+    """The optimiser step of a pair runs in the last workgroup of its linearize slice (default) or as its own launch
+    (`DGS_GICP_FUSED=0`); the partial rows are summed in the same order either way: same transforms, iterations, evaluations."""
+    import os
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=6, n_points=30000, seed=9, distinct_scans=6)
+    out = {}
+    for fused in ("1", "0"):
+        old = os.environ.get("DGS_GICP_FUSED")
+        os.environ["DGS_GICP_FUSED"] = fused
+        try:
+            r = Registration(method)
+        finally:
+            if old is None:
+                del os.environ["DGS_GICP_FUSED"]
+            else:
+                os.environ["DGS_GICP_FUSED"] = old
+        r.setInputTarget(tgt)
+        res = r.align_batch(sources, guesses)
+        r.setInputSource(sources[0])
+        r.align(guesses[0])
+        out[fused] = (res, r.getFinalTransformation(), r.last_result.iterations)
+    for a, b in zip(out["1"][0], out["0"][0]):
+        assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["evaluations"] == b["evaluations"]
+        assert a["converged"] == b["converged"] and a["fitness"] == b["fitness"]
+    assert np.array_equal(out["1"][1], out["0"][1]) and out["1"][2] == out["0"][2]
