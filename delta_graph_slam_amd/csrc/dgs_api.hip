@@ -765,7 +765,7 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const
   return DGS_OK;
 }
 
-int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
+static int voxel_filter_call(int approx, dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
                           int64_t out_capacity, int32_t out_on_device, int64_t* n_out) {
   if (!h || !n_out || n < 0 || (n > 0 && (!in_xyz16 || !out_xyz16)) || n > INT32_MAX || !(leaf_size > 0) || out_capacity < 0) return DGS_ERR_INVALID_ARGUMENT;
   h->err.clear();
@@ -786,7 +786,7 @@ int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32
     cap = n;
   }
   int64_t m = 0;
-  int rc = voxel_grid_filter(h, din, n, leaf_size, dout, cap, &m);
+  int rc = approx ? approx_voxel_grid_filter(h, din, n, leaf_size, dout, cap, &m) : voxel_grid_filter(h, din, n, leaf_size, dout, cap, &m);
   if (rc) return rc;
   *n_out = m;
   if (m > out_capacity) {
@@ -798,6 +798,16 @@ int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32
     DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
   return DGS_OK;
+}
+
+int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
+                          int64_t out_capacity, int32_t out_on_device, int64_t* n_out) {
+  return voxel_filter_call(0, h, in_xyz16, n, in_on_device, leaf_size, out_xyz16, out_capacity, out_on_device, n_out);
+}
+
+int dgs_approx_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
+                                 int64_t out_capacity, int32_t out_on_device, int64_t* n_out) {
+  return voxel_filter_call(1, h, in_xyz16, n, in_on_device, leaf_size, out_xyz16, out_capacity, out_on_device, n_out);
 }
 
 int dgs_gicp_get_covariances(dgs_handle* h, int32_t which, double* cov9) {

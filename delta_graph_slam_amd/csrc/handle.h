@@ -224,6 +224,7 @@ int side_build_now(dgs_handle* h);   // enqueues the deferred build of the targe
 // ndt_voxel.hip
 int ndt_build_target(dgs_handle* h);
 int voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, float4* out, int64_t out_capacity, int64_t* n_out);
+int approx_voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, float4* out, int64_t out_capacity, int64_t* n_out);   // pcl::ApproximateVoxelGrid
 int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]);
 int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_out6, hipStream_t st = nullptr);
 // ndt_align.hip

@@ -289,6 +289,143 @@ int voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, fl
   return DGS_OK;
 }
 
+// ---- pcl::ApproximateVoxelGrid -------------------------------------------------------------------------------
+// Upstream is ONE sequential pass through a 512-entry history table hashed by the cell coordinates: a point whose slot holds
+// another cell flushes that cell's centroid to the output and takes the slot over; the rest is flushed in slot order at the end.
+// The slots are independent of each other except for the ORDER of the output, so the pass parallelises exactly:
+//   1. stable sort of the points by slot (9 bits) -> every slot's subsequence, still in point order;
+//   2. a run = consecutive points of a subsequence with the same cell = one output point; head flags + scan number the runs;
+//   3. a run is flushed when the next run of its slot begins (trigger = index of that run's first point) or, if it is the last of
+//      its slot, in the final sweep (trigger = n + slot): sorting the runs by trigger gives upstream's output order;
+//   4. one lane per output point sums its run in point order (float, as upstream) and divides by the float count.
+constexpr unsigned kApproxHist = 512;
+
+__device__ __forceinline__ void approx_cell(const float4 p, const float inv_leaf, int& ix, int& iy, int& iz, unsigned& slot) {
+  ix = (int)floorf(p.x * inv_leaf);
+  iy = (int)floorf(p.y * inv_leaf);
+  iz = (int)floorf(p.z * inv_leaf);
+  slot = ((unsigned)ix * 7171u + (unsigned)iy * 3079u + (unsigned)iz * 4231u) & (kApproxHist - 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void approx_key_kernel(const float4* __restrict__ pts, int n, float inv_leaf, uint32_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int ix, iy, iz;
+  unsigned slot;
+  approx_cell(pts[i], inv_leaf, ix, iy, iz, slot);
+  keys[i] = slot;
+  vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kBlock) void approx_head_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ slots, const uint32_t* __restrict__ order,
+                                                             int n, float inv_leaf, int* __restrict__ head) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int h = 1;
+  if (s > 0 && slots[s - 1] == slots[s]) {
+    int ax, ay, az, bx, by, bz;
+    unsigned t;
+    approx_cell(pts[order[s]], inv_leaf, ax, ay, az, t);
+    approx_cell(pts[order[s - 1]], inv_leaf, bx, by, bz, t);
+    h = (ax != bx || ay != by || az != bz) ? 1 : 0;
+  }
+  head[s] = h;
+}
+
+__global__ __launch_bounds__(kBlock) void approx_runs_kernel(const int* __restrict__ head, const int* __restrict__ run_id, int n, uint32_t* __restrict__ run_start,
+                                                             int* __restrict__ scalars) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  if (head[s]) run_start[run_id[s] - 1] = (uint32_t)s;
+  if (s == n - 1) scalars[0] = run_id[s];
+}
+
+__global__ __launch_bounds__(kBlock) void approx_trigger_kernel(const uint32_t* __restrict__ slots, const uint32_t* __restrict__ order,
+                                                                const uint32_t* __restrict__ run_start, const int* __restrict__ scalars, int n,
+                                                                uint32_t* __restrict__ trigger, uint32_t* __restrict__ run) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int n_runs = scalars[0];
+  uint32_t t = 0xFFFFFFFFu;   // padding sorts last
+  if (r < n_runs) {
+    const uint32_t s0 = run_start[r];
+    const uint32_t slot = slots[s0];
+    t = (uint32_t)n + slot;   // the last run of its slot: flushed by the final sweep over the table
+    if (r + 1 < n_runs) {
+      const uint32_t s1 = run_start[r + 1];
+      if (slots[s1] == slot) t = order[s1];   // flushed when this point arrives
+    }
+  }
+  trigger[r] = t;
+  run[r] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(kBlock) void approx_centroid_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ order,
+                                                                 const uint32_t* __restrict__ run_start, const uint32_t* __restrict__ runs_in_output_order,
+                                                                 const int* __restrict__ scalars, int n, float4* __restrict__ out, int out_capacity) {
+#pragma clang fp contract(off)
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_runs = scalars[0];
+  if (o >= n_runs || o >= out_capacity) return;
+  const int r = (int)runs_in_output_order[o];
+  const int s0 = (int)run_start[r], s1 = (r + 1 < n_runs) ? (int)run_start[r + 1] : n;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int s = s0; s < s1; s++) {
+    const float4 p = pts[order[s]];
+    sx += p.x; sy += p.y; sz += p.z;
+  }
+  const float fn = (float)(s1 - s0);
+  out[o] = make_float4(sx / fn, sy / fn, sz / fn, 1.f);
+}
+
+// out receives the centroids in upstream's output order; *n_out their number.  The input must be finite (upstream does not look).
+int approx_voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n64, float leaf, float4* out, int64_t out_capacity, int64_t* n_out) {
+  hipStream_t st = h->stream;
+  *n_out = 0;
+  if (n64 == 0) return DGS_OK;
+  const int n = (int)n64;
+  const float inv_leaf = 1.0f / leaf;
+  DGS_HIP_TRY(h, h->key_in.reserve(n));
+  DGS_HIP_TRY(h, h->key_out.reserve(n));
+  DGS_HIP_TRY(h, h->val_in.reserve(n));
+  DGS_HIP_TRY(h, h->val_out.reserve(n));
+  DGS_HIP_TRY(h, h->vg_run_keys.reserve(n));
+  DGS_HIP_TRY(h, h->run_counts.reserve(n));
+  DGS_HIP_TRY(h, h->run_offsets.reserve(n));
+  DGS_HIP_TRY(h, h->vg_scalars.reserve(8));
+  DGS_HIP_TRY(h, h->scratch_cloud.reserve(n));   // 4 n words: the second sort's outputs live here
+  uint32_t* trig_sorted = reinterpret_cast<uint32_t*>(h->scratch_cloud.ptr);
+  uint32_t* runs_sorted = trig_sorted + n;
+  size_t t1 = 0, t2 = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, t1, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, n, 0, 32, st);
+  (void)hipcub::DeviceScan::InclusiveSum(nullptr, t2, h->run_counts.ptr, h->run_offsets.ptr, n, st);
+  DGS_HIP_TRY(h, h->cub_temp.reserve(std::max(t1, t2) + 256));
+  DGS_HIP_TRY(h, hipMemsetAsync(h->vg_scalars.ptr, 0, 8 * sizeof(int), st));
+  const int nb = (n + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(approx_key_kernel, dim3(nb), dim3(kBlock), 0, st, in, n, inv_leaf, h->key_in.ptr, h->val_in.ptr);
+  size_t tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, n, 0, 9, st));
+  hipLaunchKernelGGL(approx_head_kernel, dim3(nb), dim3(kBlock), 0, st, in, h->key_out.ptr, h->val_out.ptr, n, inv_leaf, h->run_counts.ptr);
+  tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceScan::InclusiveSum(h->cub_temp.ptr, tb, h->run_counts.ptr, h->run_offsets.ptr, n, st));
+  hipLaunchKernelGGL(approx_runs_kernel, dim3(nb), dim3(kBlock), 0, st, h->run_counts.ptr, h->run_offsets.ptr, n, h->vg_run_keys.ptr, h->vg_scalars.ptr);
+  hipLaunchKernelGGL(approx_trigger_kernel, dim3(nb), dim3(kBlock), 0, st, h->key_out.ptr, h->val_out.ptr, h->vg_run_keys.ptr, h->vg_scalars.ptr, n, h->key_in.ptr,
+                     h->val_in.ptr);
+  tb = h->cub_temp.cap;
+  DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, trig_sorted, h->val_in.ptr, runs_sorted, n, 0, 32, st));
+  hipLaunchKernelGGL(approx_centroid_kernel, dim3(nb), dim3(kBlock), 0, st, in, h->val_out.ptr, h->vg_run_keys.ptr, runs_sorted, h->vg_scalars.ptr, n, out,
+                     (int)std::min<int64_t>(out_capacity, INT32_MAX));
+  int* hs = reinterpret_cast<int*>(h->pinned);
+  if (ensure_pinned(h, 64) != DGS_OK) return DGS_ERR_HIP;
+  hs = reinterpret_cast<int*>(h->pinned);
+  DGS_HIP_TRY(h, hipMemcpyAsync(hs, h->vg_scalars.ptr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  DGS_HIP_TRY(h, hipStreamSynchronize(st));
+  DGS_HIP_TRY(h, hipGetLastError());
+  *n_out = hs[0];
+  return DGS_OK;
+}
+
 // ---- host driver -------------------------------------------------------------------------------------------
 int ndt_build_target(dgs_handle* h) {
   const int64_t n = h->nt;

@@ -7,7 +7,7 @@ Mirrors /root/reference/apps/scan_matching_odometry_nodelet.cpp:
                                 reject on !hasConverged (:222-226) or implausible jump (:231-241), keyframe switch (:249-260)
   publish_scan_matching_status :309-346  matching_error = getFitnessScore(), inlier_fraction (d^2 < 0.25)
 Down-sampling (:83-103,155-165): VOXELGRID runs on the device (pcl::VoxelGrid centroid filter, SURVEY.md §8f-2) so a raw scan
-uploaded once stays in HBM through align; NONE passes the cloud through; APPROX_VOXELGRID is not provided.
+uploaded once stays in HBM through align; APPROX_VOXELGRID (pcl::ApproximateVoxelGrid, :90-96) likewise; NONE passes the cloud through.
 
 The frame loop is inherently sequential (frame t's guess is frame t-1's result), so this path does not shard:
 "replicas only"  -- one stream per GPU if several robots / bags are processed.
@@ -55,8 +55,6 @@ class ScanMatchingOdometry:
         # filtered twice -- pass downsample_method explicitly to reproduce the nodelet
         self.downsample_method = str(pr.get("downsample_method", "NONE"))
         self.downsample_resolution = float(pr.get("downsample_resolution", 0.1))
-        if self.downsample_method == "APPROX_VOXELGRID":
-            raise NotImplementedError("APPROX_VOXELGRID is not provided; use VOXELGRID or NONE")
         if registration is None:
             from .registration import select_registration_method
             registration = select_registration_method(pr, device=device)
@@ -73,6 +71,8 @@ class ScanMatchingOdometry:
         """scan_matching_odometry_nodelet.cpp:155-165"""
         if self.downsample_method == "VOXELGRID":
             return self.registration.voxel_grid_filter(cloud, self.downsample_resolution)
+        if self.downsample_method == "APPROX_VOXELGRID":
+            return self.registration.voxel_grid_filter(cloud, self.downsample_resolution, approximate=True)
         return cloud
 
     def matching(self, stamp: float, cloud, msf_delta: Optional[np.ndarray] = None, want_status: bool = False) -> np.ndarray:

@@ -241,17 +241,19 @@ class Registration:
                                                       max_range, C.byref(s)))
         return s.value
 
-    def voxel_grid_filter(self, cloud, leaf_size: float):
-        """pcl::VoxelGrid centroid filter (scan_matching_odometry_nodelet.cpp:83-89,155-165) on the device.
+    def voxel_grid_filter(self, cloud, leaf_size: float, approximate: bool = False):
+        """pcl::VoxelGrid centroid filter (scan_matching_odometry_nodelet.cpp:83-89,155-165) -- or, with approximate=True,
+        pcl::ApproximateVoxelGrid (:90-96) -- on the device.
         numpy in -> numpy out; device tensor in -> device tensor out (no host round trip of the points)."""
+        fn = self._lib.dgs_approx_voxel_grid_filter if approximate else self._lib.dgs_voxel_grid_filter
         ptr, n, dev, keep = _cloud_ptr(cloud)
         m = C.c_int64(0)
         if dev:
             out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=cloud.device)
-            self._check(self._lib.dgs_voxel_grid_filter(self._h, ptr, n, 1, leaf_size, C.c_void_p(out.data_ptr()), n, 1, C.byref(m)))
+            self._check(fn(self._h, ptr, n, 1, leaf_size, C.c_void_p(out.data_ptr()), n, 1, C.byref(m)))
             return out[:m.value]
         out = np.empty((max(n, 1), 4), dtype=np.float32)
-        self._check(self._lib.dgs_voxel_grid_filter(self._h, ptr, n, 0, leaf_size, out.ctypes.data_as(C.c_void_p), n, 0, C.byref(m)))
+        self._check(fn(self._h, ptr, n, 0, leaf_size, out.ctypes.data_as(C.c_void_p), n, 0, C.byref(m)))
         return out[:m.value].copy()
 
     # -- batched candidates (loop_detector.hpp:137-156) ----------------------------------------------------

@@ -215,6 +215,14 @@ int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1_xyz16, int64_t n1,
 int dgs_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
                           int64_t out_capacity, int32_t out_on_device, int64_t* n_out);
 
+/* pcl::ApproximateVoxelGrid<PointXYZ>, the reference's other down-sampling choice
+ * (/root/reference/apps/scan_matching_odometry_nodelet.cpp:90-96; apps/prefiltering_nodelet.cpp:64-69): upstream's single pass
+ * through a 512-entry history table hashed by the cell, reproduced exactly -- same output points (float sums in point order,
+ * divided by the float count) in the same order: a cell is emitted when another cell evicts it from its slot, the rest in slot
+ * order at the end.  Same argument conventions as dgs_voxel_grid_filter; the input must be finite (upstream does not check). */
+int dgs_approx_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n, int32_t in_on_device, float leaf_size, float* out_xyz16,
+                                 int64_t out_capacity, int32_t out_on_device, int64_t* n_out);
+
 /* ---- several GPUs of one process: the candidate loop of LoopDetector::matching sharded across devices -------------------------
  * The reference runs loop detection inside the nodelet manager process under main_thread_mutex
  * (/root/reference/apps/delta_graph_slam_nodelet.cpp:797,816; candidate loop loop_detector.hpp:137-156), so the multi-GPU form a

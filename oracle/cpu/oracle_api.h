@@ -62,6 +62,7 @@ void orc_knn(const float* cloud, int64_t n, const float* queries, int64_t m, int
 void orc_se3_exp(const double* a6, double* T16_rowmajor);
 /* pcl::VoxelGrid centroid filter; out must hold n points; returns the number of cells */
 int64_t orc_voxel_grid(const float* xyz16, int64_t n, float leaf, float* out_xyz16);
+int64_t orc_approx_voxel_grid(const float* xyz16, int64_t n, float leaf, float* out_xyz16);   // pcl::ApproximateVoxelGrid; finite input
 
 #ifdef __cplusplus
 }

@@ -54,3 +54,41 @@ extern "C" int64_t orc_voxel_grid(const float* xyz16, int64_t n, float leaf, flo
   }
   return m;
 }
+
+// CPU restatement of pcl::ApproximateVoxelGrid<pcl::PointXYZ>::applyFilter (PCL 1.8-1.12 filters/impl/approximate_voxel_grid.hpp),
+// the reference's other down-sampling choice (/root/reference/apps/scan_matching_odometry_nodelet.cpp:90-96,
+// apps/prefiltering_nodelet.cpp:64-69): one pass over the points in order through a 512-entry history table hashed by the
+// cell coordinates; a point whose table slot holds ANOTHER cell flushes that cell's centroid (float sums, divided by the float
+// count) to the output and takes the slot over; what is left in the table at the end is flushed in slot order.  PCL is absent
+// from /root/reference and from this image: parity unpinned, like the rest of oracle/.
+extern "C" int64_t orc_approx_voxel_grid(const float* xyz16, int64_t n, float leaf, float* out_xyz16) {
+  constexpr int kHist = 512;
+  struct He { int ix, iy, iz, count; float c[3]; };
+  std::vector<He> hist(kHist);
+  for (auto& e : hist) { e.count = 0; e.c[0] = e.c[1] = e.c[2] = 0.f; e.ix = e.iy = e.iz = 0; }
+  const float inv = 1.0f / leaf;
+  int64_t op = 0;
+  auto flush = [&](He& e) {
+    const float cnt = static_cast<float>(e.count);
+    for (int a = 0; a < 3; a++) out_xyz16[op * 4 + a] = e.c[a] / cnt;
+    out_xyz16[op * 4 + 3] = 1.0f;
+    op++;
+  };
+  for (int64_t cp = 0; cp < n; cp++) {
+    const float* p = xyz16 + cp * 4;
+    const int ix = static_cast<int>(std::floor(p[0] * inv)), iy = static_cast<int>(std::floor(p[1] * inv)), iz = static_cast<int>(std::floor(p[2] * inv));
+    const unsigned hash = (static_cast<unsigned>(ix) * 7171u + static_cast<unsigned>(iy) * 3079u + static_cast<unsigned>(iz) * 4231u) & (kHist - 1);
+    He& e = hist[hash];
+    if (e.count && (ix != e.ix || iy != e.iy || iz != e.iz)) {
+      flush(e);
+      e.count = 0;
+      e.c[0] = e.c[1] = e.c[2] = 0.f;
+    }
+    e.ix = ix; e.iy = iy; e.iz = iz;
+    e.count++;
+    for (int a = 0; a < 3; a++) e.c[a] += p[a];
+  }
+  for (auto& e : hist)
+    if (e.count) flush(e);
+  return op;
+}

@@ -368,3 +368,13 @@ def voxel_grid(cloud, leaf: float) -> np.ndarray:
     L.orc_voxel_grid.restype = C.c_int64
     m = L.orc_voxel_grid(pc, C.c_int64(c.shape[0]), C.c_float(leaf), out.ctypes.data_as(C.POINTER(C.c_float)))
     return out[:m].copy()
+
+
+def approx_voxel_grid(cloud, leaf: float) -> np.ndarray:
+    """pcl::ApproximateVoxelGrid (restatement in oracle/cpu/voxelgrid_cpu.cpp); the input must be finite."""
+    c, pc = _f32c(cloud)
+    out = np.empty((max(c.shape[0], 1), 4), np.float32)
+    L = lib()
+    L.orc_approx_voxel_grid.restype = C.c_int64
+    m = L.orc_approx_voxel_grid(pc, C.c_int64(c.shape[0]), C.c_float(leaf), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:m].copy()

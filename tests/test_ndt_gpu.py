@@ -240,3 +240,42 @@ def test_device_tensors_may_die_right_after_the_call(reg_cls, oracle_lib):
     h.setInputSource(src)
     h.align()
     assert np.array_equal(r.getFinalTransformation(), h.getFinalTransformation()) and len(junk) == 16
+
+
+@pytest.mark.parametrize("leaf", [0.1, 0.5, 2.0])
+def test_approx_voxel_grid_filter_matches_oracle(reg_cls, oracle_lib, leaf):
+    """pcl::ApproximateVoxelGrid (scan_matching_odometry_nodelet.cpp:90-96) on the device: the sequential history-table pass is
+    reproduced exactly -- same centroids, same float bits, same output ORDER -- by sorts over slots and flush triggers."""
+    import torch
+    xyz, _ = synth.street_scan((0.0, 0.0, 0.0), 64, (2.0, -24.8), 1024, 5)
+    scan = synth._xyz1(xyz)
+    rng = np.random.default_rng(1)
+    rnd = np.ones((30000, 4), np.float32)
+    rnd[:, :3] = (rng.normal(0, 8, (30000, 3)) * [1, 1, 0.1]).astype(np.float32)
+    one_cell = np.ones((700, 4), np.float32)
+    one_cell[:, :3] = rng.uniform(0.01, 0.09, (700, 3))
+    r = reg_cls("NDT_OMP")
+    for cloud in (scan, rnd, rnd[rng.permutation(30000)], one_cell, rnd[:1]):
+        ref = oracle_lib.approx_voxel_grid(cloud, leaf)
+        out = r.voxel_grid_filter(cloud, leaf, approximate=True)
+        assert out.shape == ref.shape and np.array_equal(out, ref)
+        dout = r.voxel_grid_filter(torch.from_numpy(cloud).cuda(), leaf, approximate=True)
+        assert dout.is_cuda and np.array_equal(dout.cpu().numpy(), ref)
+    assert r.voxel_grid_filter(np.zeros((0, 4), np.float32), leaf, approximate=True).shape == (0, 4)
+
+
+def test_odometry_runs_with_the_approximate_voxel_grid(reg_cls):
+    """downsample_method = APPROX_VOXELGRID (scan_matching_odometry_nodelet.cpp:90-96) through the odometry mirror."""
+    from delta_graph_slam_amd.odometry import ScanMatchingOdometry
+    clouds, poses = synth.vlp16_stream(n_frames=5)
+    odo = ScanMatchingOdometry(reg_cls("FAST_GICP", gicp_max_correspondence_distance=2.0),
+                               dict(downsample_method="APPROX_VOXELGRID", downsample_resolution=0.2, keyframe_delta_trans=1.0, keyframe_delta_angle=1.0,
+                                    keyframe_delta_time=1e9))
+    ref = ScanMatchingOdometry(reg_cls("FAST_GICP", gicp_max_correspondence_distance=2.0),
+                               dict(downsample_method="VOXELGRID", downsample_resolution=0.2, keyframe_delta_trans=1.0, keyframe_delta_angle=1.0,
+                                    keyframe_delta_time=1e9))
+    a = [odo.matching(0.1 * k, c) for k, c in enumerate(clouds)]       # matching() filters the scan itself (:184)
+    b = [ref.matching(0.1 * k, c) for k, c in enumerate(clouds)]
+    moved = np.linalg.norm(b[-1][:3, 3])
+    assert moved > 0.05
+    assert np.linalg.norm(a[-1][:3, 3] - b[-1][:3, 3]) < 0.05 + 0.1 * moved    # two down-samplings of the same scans: the same motion

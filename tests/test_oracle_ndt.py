@@ -169,3 +169,41 @@ def test_matches_committed_goldens():
     vox = v.voxels()
     assert np.array_equal(vox["keys"], GOLD["ndt_vox_keys"]) and np.array_equal(vox["counts"], GOLD["ndt_vox_counts"])
     assert np.allclose(vox["mean"], GOLD["ndt_vox_mean"], atol=1e-12)
+
+
+def test_approx_voxel_grid_restatement_vs_a_plain_python_pass():
+    """pcl::ApproximateVoxelGrid (oracle/cpu/voxelgrid_cpu.cpp) against an independent statement of the same pass written with a
+    Python dict of table slots: same points, same order, same float bits."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(3)
+    cloud = np.ones((4000, 4), np.float32)
+    cloud[:, :3] = (rng.normal(0, 6, (4000, 3)) * [1, 1, 0.2]).astype(np.float32)
+    cloud[1000:2000, :3] = cloud[:1000, :3] + np.float32(0.01)          # revisits of the same cells much later
+    for leaf in (0.25, 1.0, 3.0):
+        inv = np.float32(1.0) / np.float32(leaf)
+        table = {}
+        out = []
+
+        def flush(e):
+            out.append([e[4] / np.float32(e[3]), e[5] / np.float32(e[3]), e[6] / np.float32(e[3]), np.float32(1.0)])
+
+        for p in cloud:
+            ix, iy, iz = (int(np.floor(p[a] * inv)) for a in range(3))
+            slot = (ix * 7171 + iy * 3079 + iz * 4231) & 511
+            e = table.get(slot)
+            if e is not None and e[3] and (e[0], e[1], e[2]) != (ix, iy, iz):
+                flush(e)
+                e = None
+            if e is None:
+                e = [ix, iy, iz, 0, np.float32(0), np.float32(0), np.float32(0)]
+                table[slot] = e
+            e[0], e[1], e[2] = ix, iy, iz
+            e[3] += 1
+            e[4] = np.float32(e[4] + p[0]); e[5] = np.float32(e[5] + p[1]); e[6] = np.float32(e[6] + p[2])
+        for slot in sorted(table):
+            if table[slot][3]:
+                flush(table[slot])
+        want = np.array(out, np.float32)
+        got = orc.approx_voxel_grid(cloud, leaf)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        assert got.shape[0] < cloud.shape[0]
