@@ -431,7 +431,14 @@ __global__ __launch_bounds__(kBlock, 4) void ndt_derivatives_kernel(const float4
 // vectors, then per neighbour voxel q = float(double(x') - mean), C = float(icov) (all 9 entries: after the eigenvalue clamp
 // the covariance is rebuilt as V diag V^-1 and is not exactly symmetric), q^T C, exp, the float 3x6 product C * J, the float
 // gradient / Hessian increments, each converted and added to the point's DOUBLE totals.  One point -> 43 doubles.
-template <int SEARCH>
+// LITERAL = false (default): the same values with upstream's structural zeros and ones not multiplied out -- the point gradient
+// is [I | J3 J4 J5] with a zero in J3's first row, the point Hessian is zero outside its 3x3 rotational block: 1 * a, a + 0 and
+// 0 * a are exact whenever a is finite, so C * J, x^T C H and J^T C J shrink from ~800 to ~450 float operations per voxel and the
+// register copy of the 6x6x3 point Hessian to its 6 distinct vectors.  Every operation that remains is upstream's, in upstream's
+// order.  Bit-identical to LITERAL = true (DGS_NDT_STRICT_LITERAL=1; test_strict_gpu.py::test_structural_zero_shortcuts_are_bit_identical)
+// as long as the float products stay finite; where one overflows upstream turns 0 * inf into NaN and this path keeps inf -- both
+// end in a non-finite Hessian and a failed registration.
+template <int SEARCH, bool LITERAL>
 __device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T, const NdtPair& st, const VoxelGrid& g, const double* __restrict__ vtab,
                                                  const double gauss_d1, const float gd2, const int leaf_pow2, const bool need_h, double* out) {
 #pragma unroll
@@ -454,40 +461,56 @@ __device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T,
   pg[1][3] = xj[0]; pg[2][3] = xj[1];
   pg[0][4] = xj[2]; pg[1][4] = xj[3]; pg[2][4] = xj[4];
   pg[0][5] = xj[5]; pg[1][5] = xj[6]; pg[2][5] = xj[7];
-  float ph[6][6][3];
+  // the 6 distinct vectors of the point Hessian's rotational block: (3,3) (3,4) (3,5) (4,4) (4,5) (5,5); zero without a Hessian
+  float hv[6][3];
 #pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = 0; j < 6; j++) ph[i][j][0] = ph[i][j][1] = ph[i][j][2] = 0.f;
+  for (int i = 0; i < 6; i++) hv[i][0] = hv[i][1] = hv[i][2] = 0.f;
   if (need_h) {
     float xh[15];
 #pragma unroll
     for (int i = 0; i < 15; i++) xh[i] = st.hang[i][0] * xp[0] + st.hang[i][1] * xp[1] + st.hang[i][2] * xp[2];
-    const float a[3] = {0, xh[0], xh[1]}, b[3] = {0, xh[2], xh[3]}, c[3] = {0, xh[4], xh[5]};
-    const float d[3] = {xh[6], xh[7], xh[8]}, e[3] = {xh[9], xh[10], xh[11]}, f[3] = {xh[12], xh[13], xh[14]};
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      ph[3][3][r] = a[r]; ph[3][4][r] = b[r]; ph[3][5][r] = c[r];
-      ph[4][3][r] = b[r]; ph[4][4][r] = d[r]; ph[4][5][r] = e[r];
-      ph[5][3][r] = c[r]; ph[5][4][r] = e[r]; ph[5][5][r] = f[r];
-    }
+    hv[0][1] = xh[0]; hv[0][2] = xh[1];     // a = (0, xh0, xh1)
+    hv[1][1] = xh[2]; hv[1][2] = xh[3];     // b
+    hv[2][1] = xh[4]; hv[2][2] = xh[5];     // c
+    hv[3][0] = xh[6]; hv[3][1] = xh[7]; hv[3][2] = xh[8];       // d
+    hv[4][0] = xh[9]; hv[4][1] = xh[10]; hv[4][2] = xh[11];     // e
+    hv[5][0] = xh[12]; hv[5][1] = xh[13]; hv[5][2] = xh[14];    // f
   }
+  // (i, j) of the rotational block -> its vector
+  auto hvec = [&](int i, int j) -> const float* {
+    const int lo = (i < j ? i : j) - 3, hi = (i < j ? j : i) - 3;
+    return hv[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+  };
   double score_pt = 0.0, g_pt[6] = {0, 0, 0, 0, 0, 0}, h_pt[36];
 #pragma unroll
   for (int k = 0; k < 36; k++) h_pt[k] = 0.0;
-#pragma unroll 1
+  // the neighbourhood's voxel ids first (independent loads, issued together): at 2 waves per SIMD (172 VGPRs are the double totals of
+  // the point and of the thread) little else hides the table's latency.  (Loading the next voxel's record one iteration ahead was
+  // tried: 24 more live registers, 1 wave per SIMD, 15 -> 19.7 ms per step.)
+  int vids[NB];
+#pragma unroll
   for (int k = 0; k < NB; k++) {
     int dx, dy, dz;
     neighbour_offset<SEARCH>(k, dx, dy, dz);
     const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
     const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
-    const int vid = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
-    if (vid < 0) continue;
-    if (SEARCH == DGS_NDT_KDTREE) {
-      const float4 ce = g.centroid[vid];
+    vids[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+  }
+  if (SEARCH == DGS_NDT_KDTREE) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (vids[k] < 0) continue;
+      const float4 ce = g.centroid[vids[k]];
       const float ex = ce.x - xt[0], ey = ce.y - xt[1], ez = ce.z - xt[2];
-      if (!(ex * ex + ey * ey + ez * ez < r2)) continue;
+      if (!(ex * ex + ey * ey + ez * ez < r2)) vids[k] = -1;
     }
+  }
+#pragma unroll 1
+  for (int k = 0; k < NB; k++) {
+    int vid = vids[0];   // vids stays in registers: a dynamic subscript is a chain of selects, not scratch memory
+#pragma unroll
+    for (int j = 1; j < NB; j++) vid = (k == j) ? vids[j] : vid;
+    if (vid < 0) continue;
     const double* __restrict__ rec = vtab + (size_t)vid * 12;  // mean[3], icov[9] (row-major), double
     float q[3], C[3][3];
 #pragma unroll
@@ -505,24 +528,58 @@ __device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T,
     if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
     e_x_cov_x = (float)((double)e_x_cov_x * gauss_d1);
     float cPG[3][6];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) cPG[r][c] = C[r][0] * pg[0][c] + C[r][1] * pg[1][c] + C[r][2] * pg[2][c];
     float g6[6];
+    constexpr bool literal = LITERAL;
+    if (!LITERAL) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        cPG[r][0] = C[r][0]; cPG[r][1] = C[r][1]; cPG[r][2] = C[r][2];            // C * (unit column): exact
+        cPG[r][3] = C[r][1] * pg[1][3] + C[r][2] * pg[2][3];                      // (C0 * 0 + m1) + m2
+#pragma unroll
+        for (int c = 4; c < 6; c++) cPG[r][c] = C[r][0] * pg[0][c] + C[r][1] * pg[1][c] + C[r][2] * pg[2][c];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) cPG[r][c] = C[r][0] * pg[0][c] + C[r][1] * pg[1][c] + C[r][2] * pg[2][c];
+    }
 #pragma unroll
     for (int c = 0; c < 6; c++) g6[c] = q[0] * cPG[0][c] + q[1] * cPG[1][c] + q[2] * cPG[2][c];
 #pragma unroll
     for (int c = 0; c < 6; c++) g_pt[c] += (double)(e_x_cov_x * g6[c]);
     if (need_h) {
+      if (literal) {
 #pragma unroll
-      for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          const float xCH = qC[0] * ph[i][j][0] + qC[1] * ph[i][j][1] + qC[2] * ph[i][j][2];
-          const float pcp = pg[0][j] * cPG[0][i] + pg[1][j] * cPG[1][i] + pg[2][j] * cPG[2][i];
-          h_pt[i * 6 + j] += (double)(e_x_cov_x * (-gd2 * g6[i] * g6[j] + xCH + pcp));
-        }
+          for (int j = 0; j < 6; j++) {
+            float xCH = qC[0] * 0.f + qC[1] * 0.f + qC[2] * 0.f;
+            if (i >= 3 && j >= 3) {
+              const float* v = hvec(i, j);
+              xCH = qC[0] * v[0] + qC[1] * v[1] + qC[2] * v[2];
+            }
+            const float pcp = pg[0][j] * cPG[0][i] + pg[1][j] * cPG[1][i] + pg[2][j] * cPG[2][i];
+            h_pt[i * 6 + j] += (double)(e_x_cov_x * (-gd2 * g6[i] * g6[j] + xCH + pcp));
+          }
+      } else {
+        float xch[6];   // x^T C H for the 6 distinct vectors
+#pragma unroll
+        for (int v = 0; v < 6; v++) xch[v] = qC[0] * hv[v][0] + qC[1] * hv[v][1] + qC[2] * hv[v][2];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+          for (int j = 0; j < 6; j++) {
+            float t = -gd2 * g6[i] * g6[j];
+            if (i >= 3 && j >= 3) {
+              const int lo = (i < j ? i : j) - 3, hi = (i < j ? j : i) - 3;
+              t = t + xch[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+            }
+            // J^T C J: column j of J is a unit vector for j < 3, has a zero first entry for j == 3
+            const float pcp = (j < 3) ? cPG[j][i] : (j == 3) ? (pg[1][3] * cPG[1][i] + pg[2][3] * cPG[2][i]) : (pg[0][j] * cPG[0][i] + pg[1][j] * cPG[1][i] + pg[2][j] * cPG[2][i]);
+            h_pt[i * 6 + j] += (double)(e_x_cov_x * (t + pcp));
+          }
+      }
     }
     score_pt += (double)score_inc;
   }
@@ -536,8 +593,8 @@ __device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T,
 // ROWS = false (ndt_strict_order 1): per-thread double totals over a strided set of points, block sums in a fixed order, one
 // 48-double row per workgroup.  ROWS = true (ndt_strict_order 2): the 43 per-point totals go to HBM, column-major per pair
 // ([43][max_n]), for the sequential index-order sum of ndt_strict_seqsum_kernel.
-template <int SEARCH, bool ROWS>
-__global__ __launch_bounds__(kBlock) void ndt_derivatives_strict_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
+template <int SEARCH, bool ROWS, bool LITERAL>
+__global__ __launch_bounds__(kBlock, 2) void ndt_derivatives_strict_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
                                                                         const NdtPair* __restrict__ pairs, const VoxelGrid g,
                                                                         const double* __restrict__ vtab, const double gauss_d1, const float gd2,
                                                                         const int leaf_pow2, double* __restrict__ partials, double* __restrict__ rows,
@@ -559,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void ndt_derivatives_strict_kernel(const fl
   const int ncol = need_h ? kStrictAccum : 7;
   for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
     double o[kStrictAccum];
-    ndt_point_strict<SEARCH>(src[i], T, st, g, vtab, gauss_d1, gd2, leaf_pow2, need_h, o);
+    ndt_point_strict<SEARCH, LITERAL>(src[i], T, st, g, vtab, gauss_d1, gd2, leaf_pow2, need_h, o);
     if (ROWS) {
       double* __restrict__ col = rows + (size_t)pair * kStrictAccum * max_n + i;
       for (int k = 0; k < ncol; k++) col[(size_t)k * max_n] = o[k];
@@ -1150,12 +1207,16 @@ template <int SEARCH>
 static void launch_strict(dgs_handle* h, const NdtLaunch& L, const dim3 grid, const int leaf_pow2) {
   const double gd1 = h->consts.gauss_d1;
   const float gd2 = (float)h->consts.gauss_d2;
-  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL)
-    hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                       h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
-  else
-    hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, false>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid,
-                       h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr);
+  static const bool literal = std::getenv("DGS_NDT_STRICT_LITERAL") && std::atoi(std::getenv("DGS_NDT_STRICT_LITERAL")) != 0;
+#define DGS_LAUNCH_STRICT(ROWS, LIT)                                                                                                                       \
+  hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, ROWS, LIT>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, \
+                     h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr)
+  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) {
+    if (literal) DGS_LAUNCH_STRICT(true, true); else DGS_LAUNCH_STRICT(true, false);
+  } else {
+    if (literal) DGS_LAUNCH_STRICT(false, true); else DGS_LAUNCH_STRICT(false, false);
+  }
+#undef DGS_LAUNCH_STRICT
 }
 
 // launch >= 0: fused launch number `launch` of this align (derivatives + closing workgroups); < 0: derivatives only

@@ -156,3 +156,39 @@ def test_cfg4_shard_shape_32_candidates_of_65536_points(oracle_lib):
             assert bt > TOL_TRANS or br > TOL_ROT, (c, dt, dr, bt, br)
             assert dt <= 4 * bt + TOL_TRANS and dr <= 4 * br + TOL_ROT, (c, dt, dr, bt, br)
     assert inside >= 16
+
+
+def test_structural_zero_shortcuts_are_bit_identical():
+    """The upstream-order kernel skips upstream's multiplications by the structural zeros / ones of the point gradient and point
+    Hessian (exact for finite operands); `DGS_NDT_STRICT_LITERAL=1` multiplies them out.  Same bits: score, gradient, the full
+    non-symmetric 6x6 Hessian at several poses, and the final transforms of a batch."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+from delta_graph_slam_amd import synth, _lib as L
+from delta_graph_slam_amd.registration import Registration
+tgt, sources, guesses, _ = synth.loop_batch(n_candidates=4, n_points=30000, seed=3, distinct_scans=4)
+out = {}
+for method in ("DIRECT7", "DIRECT1", "KDTREE"):
+    r = Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=1, ndt_search_method=L.NDT_SEARCH[method])
+    r.setInputTarget(tgt)
+    r.setInputSource(sources[0])
+    for k, p in enumerate(([0, 0, 0, 0, 0, 0], [0.3, -0.2, 0.05, 0.01, -0.02, 0.4])):
+        s, g, H = r.ndt_derivatives(np.array(p, np.float64))
+        out["%%s_%%d" %% (method, k)] = [float(s).hex()] + [float(v).hex() for v in g] + [float(v).hex() for v in H.ravel()]
+r = Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=1)
+r.setInputTarget(tgt)
+res = r.align_batch(sources, guesses)
+out["batch"] = [[float(v).hex() for v in np.asarray(x["T"], np.float64).ravel()] + [x["iterations"], x["evaluations"]] for x in res]
+print(json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for lit in ("0", "1"):
+        env = dict(os.environ, DGS_NDT_STRICT_LITERAL=lit)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[lit] = p.stdout.strip().splitlines()[-1]
+    assert res["0"] == res["1"]
