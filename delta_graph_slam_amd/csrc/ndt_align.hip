@@ -823,12 +823,14 @@ __device__ inline double dot6(const double* a, const double* b) {
 
 // Starts one outer iteration from (score, grad, hess) at s.p.  Returns true when an evaluation was queued,
 // false when the iteration finished without one (zero step) or the registration ended.
+template <bool SVD_REGS>
 __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
   double neg_g[6], delta[6], rc;
 #pragma unroll
   for (int k = 0; k < 6; k++) neg_g[k] = -s.grad[k];
   if (c.strict_order) {  // JacobiSVD(H).solve(-g), the sequence of operations of the CPU checker
-    svd_solve6_dev(s.hess, neg_g, delta, 1e-17, 60);
+    if (SVD_REGS) svd_solve6_regs_dev(s.hess, neg_g, delta, 1e-17, 60);
+    else svd_solve6_dev(s.hess, neg_g, delta, 1e-17, 60);
   } else {
     gj_solve6_wave(s.hess, neg_g, delta, &rc);
     if (!(rc > 1e-13)) svd_solve6_dev(s.hess, neg_g, delta);
@@ -919,6 +921,8 @@ __device__ __forceinline__ void queue_trial(NdtPair* st, NdtSolver& s, const Ndt
 
 // Consumes one evaluation result (already stored in s.score/grad/hess) and advances the state machine until
 // the next evaluation is queued or the registration is finished.  Executed by all lanes of one wave in lock step.
+// SVD_REGS: the stand-alone solve launch of the validation modes keeps the SVD workspace in registers (solve6.h)
+template <bool SVD_REGS = false>
 __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
   s.evaluations++;
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
@@ -974,7 +978,7 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const Ndt
     if (iteration_open) {
       if (end_iteration(st, s, c, writer)) return;
     }
-    if (begin_iteration(st, s, c, writer)) return;  // evaluation queued
+    if (begin_iteration<SVD_REGS>(st, s, c, writer)) return;  // evaluation queued
     if (s.phase == PH_DONE) return;
     iteration_open = true;                          // zero-step iteration: close it and try again
   }
@@ -1093,7 +1097,7 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
 #pragma unroll
     for (int k = 0; k < 36; k++) s.hess[k] = tot[7 + k];  // upstream's full 6x6 (not exactly symmetric in float)
   }
-  ndt_advance(st, s, c, writer);
+  ndt_advance<true>(st, s, c, writer);
   if (writer) {
     st->s = s;
     if (s.phase == PH_DONE) {

@@ -100,6 +100,63 @@ __device__ __forceinline__ void svd_solve6_dev(const double* A, const double* b,
 }
 
 
+// The same solve with U and V in REGISTERS: every loop over rows / column pairs is unrolled so that all subscripts are static
+// (144 VGPRs).  For the stand-alone solve launch of the NDT validation modes only: there the LDS copy above makes every rotation a
+// chain of ~30 LDS round trips (190 us per Newton step) and nothing else shares the kernel's register budget.  Same operations in
+// the same order as svd_solve6_dev.
+__device__ __forceinline__ void svd_solve6_regs_dev(const double* A, const double* b, double* x, const double skip_tol, const int max_sweeps) {
+#pragma clang fp contract(off)
+  double U[36], V[36];
+#pragma unroll
+  for (int i = 0; i < 36; i++) { U[i] = A[i]; V[i] = (i % 7 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < max_sweeps; sweep++) {
+    bool rotated = false;
+#pragma unroll
+    for (int p = 0; p < 5; p++)
+#pragma unroll
+      for (int q = p + 1; q < 6; q++) {
+        double al = 0, be = 0, ga = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { al += U[k * 6 + p] * U[k * 6 + p]; be += U[k * 6 + q] * U[k * 6 + q]; ga += U[k * 6 + p] * U[k * 6 + q]; }
+        if (ga == 0.0 || fabs(ga) <= skip_tol * sqrt(al * be)) continue;
+        rotated = true;
+        const double ze = (be - al) / (2.0 * ga);
+        const double t = (ze >= 0 ? 1.0 : -1.0) / (fabs(ze) + sqrt(1.0 + ze * ze));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          const double up = U[k * 6 + p], uq = U[k * 6 + q];
+          U[k * 6 + p] = c * up - s * uq; U[k * 6 + q] = s * up + c * uq;
+          const double vp = V[k * 6 + p], vq = V[k * 6 + q];
+          V[k * 6 + p] = c * vp - s * vq; V[k * 6 + q] = s * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double sv[6], smax = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double s2 = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) s2 += U[k * 6 + j] * U[k * 6 + j];
+    sv[j] = sqrt(s2);
+    smax = fmax(smax, sv[j]);
+  }
+  const double thr = fmax(smax * 6.0 * DBL_EPSILON, DBL_MIN);
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    if (!(sv[j] > thr)) continue;
+    double ub = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) ub += U[k * 6 + j] * b[k];
+    const double coef = ub / (sv[j] * sv[j]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] += V[i * 6 + j] * coef;
+  }
+}
+
 // x = A^-1 b with the pseudo-inverse fallback Eigen's JacobiSVD::solve would give on a singular A (wave-uniform)
 __device__ __forceinline__ void solve6_wave(const double* A, const double* b, double* x) {
   double rc;
