@@ -128,7 +128,7 @@ class LoopDetector:
         if len(candidates) == 0:
             return np.zeros((0, 4, 4), np.float32)
         inv_new = np.linalg.inv(np.asarray(new_keyframe.estimate, np.float64))
-        est = np.stack([np.asarray(k.estimate, np.float64) for k in candidates])
+        est = np.array([k.estimate for k in candidates], dtype=np.float64)      # [n,3,3] in one conversion
         return transform2Dto3D_batch((inv_new @ est).astype(np.float32))
 
     # ---------------------------------------------------------------------------------------------- sharding
@@ -172,10 +172,9 @@ class LoopDetector:
             dist.all_gather_into_tensor(gathered, local, group=self.group)   # the path's one exchange step
             allrec = gathered.cpu().numpy()
         out = np.full((n, RECORD_WIDTH), -1.0, dtype=np.float64)
-        for row in allrec:
-            c = int(row[0])
-            if 0 <= c < n:
-                out[c] = row
+        idx = allrec[:, 0].astype(np.int64)
+        ok = (idx >= 0) & (idx < n)          # padding rows of the gather carry -1
+        out[idx[ok]] = allrec[ok]
         self.last_records = out
         return out
 
