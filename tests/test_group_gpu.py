@@ -88,3 +88,21 @@ def test_group_failures_stay_per_candidate(batch):
     res = g.align_batch(srcs, guesses[:3])
     assert res[0]["converged"] and res[2]["converged"] and not res[1]["converged"] and res[1]["status"] == 4
     assert np.array_equal(res[1]["T"], guesses[1])
+
+
+def test_group_of_eight_members_with_more_and_fewer_candidates_than_members():
+    """The 8-GPU node's shape rehearsed on one card: 8 members (device 0 listed 8 times: 8 handles, 8 host threads, 8 streams, host
+    gather), 21 candidates (ragged shares 3,3,3,3,3,2,2,2) and 5 candidates (three members idle): records in candidate order,
+    equal to the single handle's."""
+    from delta_graph_slam_amd.registration import Registration, RegistrationGroup
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=21, n_points=8192, seed=17, distinct_scans=5)
+    r = Registration("NDT_OMP", ndt_resolution=1.0)
+    r.setInputTarget(tgt)
+    ref = r.align_batch(sources, guesses)
+    g = RegistrationGroup("NDT_OMP", devices=[0] * 8, ndt_resolution=1.0)
+    assert len(g.devices) == 8
+    g.setInputTarget(tgt)
+    _same(g.align_batch(sources, guesses), ref)
+    _same(g.align_batch(sources[:5], guesses[:5]), ref[:5])
+    fit = [x["fitness"] if x["converged"] else np.inf for x in ref[:5]]
+    assert g.best_index == int(4 - np.argmin(fit[::-1])) and g.best_score == min(fit)
