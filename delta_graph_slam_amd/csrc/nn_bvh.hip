@@ -70,9 +70,18 @@ __global__ __launch_bounds__(kBlock) void gather_index_kernel(const float4* __re
 // loop-closure batch builds the target's index on the side stream while the candidates iterate).
 //
 // The tree's layout fixes the ranks: a range of W = 8 * 2^m slots splits at slot W / 2; the cloud fills the slots from the
-// left, so every range is full except the last.  Levels with W > kKdChunk are one global radix sort each on the key
+// left, so every range is full except the last.  Levels with W > kKdChunk (2,048 slots) are one global radix sort each on the key
 // (range number, coordinate along the range's widest axis); from W = kKdChunk down one workgroup per chunk sorts in LDS.
-constexpr int kKdChunk = 4096, kKdThreads = 1024, kKdPer = kKdChunk / kKdThreads;
+// chunk / workgroup size of the LDS levels, measured on the bench step (the build shares the chip with the iteration launches, so
+// what counts is how little it disturbs them): 4096 / 1024 13.9 k registrations/s, 4096 / 512 13.8 k, 2048 / 512 14.2-14.4 k,
+// 2048 / 256 14.0 k, 1024 / 256 14.3 k, 1024 / 512 14.2 k, 8192 / 1024 13.1 k
+#ifndef DGS_KD_CHUNK
+#define DGS_KD_CHUNK 2048
+#endif
+#ifndef DGS_KD_THREADS
+#define DGS_KD_THREADS 512
+#endif
+constexpr int kKdChunk = DGS_KD_CHUNK, kKdThreads = DGS_KD_THREADS, kKdPer = kKdChunk / kKdThreads;
 
 __device__ __forceinline__ unsigned orderable_f32(float f) {   // monotone float -> unsigned (finite values and infinities)
   const unsigned u = __float_as_uint(f);

@@ -308,7 +308,7 @@ def _kd_registration(method="NDT_OMP", **kw):
 
 
 def test_kd_ordered_index_is_exact_at_full_size(scans):
-    """The k-d ordered tree (nn_bvh.hip: a global sort per level above 4,096 points, bitonic sorts in LDS below) answers exactly
+    """The k-d ordered tree (nn_bvh.hip: a global sort per level above 2,048 points, bitonic sorts in LDS below) answers exactly
     like the Hilbert ordered one: aligned scans, far outliers, shuffled queries, non-finite queries, indices included."""
     from delta_graph_slam_amd.registration import Registration
     tgt, sources, _, gts = scans
@@ -335,9 +335,9 @@ def test_kd_ordered_index_is_exact_at_full_size(scans):
     assert np.array_equal(ih, ik)            # ties -> lowest index in both
 
 
-@pytest.mark.parametrize("n", [1, 5, 8, 9, 63, 64, 65, 511, 513, 4095, 4096, 4097, 8191, 8193, 20000, 70001, 200000])
+@pytest.mark.parametrize("n", [1, 5, 8, 9, 63, 64, 65, 511, 513, 2047, 2048, 2049, 4095, 4097, 8191, 8193, 20000, 70001, 200000])
 def test_kd_ordered_index_on_every_size_class(n):
-    """Sizes around the leaf (8), the LDS chunk (4,096) and the global levels; targets with duplicates and non-finite points."""
+    """Sizes around the leaf (8), the LDS chunk (2,048) and the global levels; targets with duplicates and non-finite points."""
     from scipy.spatial import cKDTree
     rng = np.random.default_rng(n)
     tgt = np.ones((n, 4), np.float32)
