@@ -27,8 +27,7 @@ struct Bvh {
   DevBuf<float4> node_hi;
   DevBuf<uint32_t> keys, keys_alt;
   DevBuf<uint32_t> vals, vals_alt;
-  DevBuf<unsigned long long> kd_keys, kd_keys_alt;   // k-d order build: (range, coordinate) keys of the global levels
-  DevBuf<unsigned> kd_bbox;                          // ... and the boxes of the ranges of the current level
+  DevBuf<unsigned> kd_bbox;   // k-d order build: boxes of the ranges of the current level
   bool kd = false;          // points are in k-d (median split) order instead of Hilbert order
   bool valid = false;
 };
@@ -87,7 +86,7 @@ struct CloudState {
     pts.release(); cov.release();
     bvh.sorted.release(); bvh.node_lo.release(); bvh.node_hi.release();
     bvh.keys.release(); bvh.keys_alt.release(); bvh.vals.release(); bvh.vals_alt.release();
-    bvh.kd_keys.release(); bvh.kd_keys_alt.release(); bvh.kd_bbox.release();
+    bvh.kd_bbox.release();
     n = 0;
     invalidate();
   }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void gather_index_kernel(const float4* __re
 // loop-closure batch builds the target's index on the side stream while the candidates iterate).
 //
 // The tree's layout fixes the ranks: a range of W = 8 * 2^m slots splits at slot W / 2; the cloud fills the slots from the
-// left, so every range is full except the last.  Levels with W > kKdChunk (2,048 slots) are one global radix sort each on the key
+// left, so every range is full except the last.  Levels with W > kKdChunk (2,048 slots) are one global sort each on the 32-bit key
 // (range number, coordinate along the range's widest axis); from W = kKdChunk down one workgroup per chunk sorts in LDS.
 // chunk / workgroup size of the LDS levels, measured on the bench step (the build shares the chip with the iteration launches, so
 // what counts is how little it disturbs them): 4096 / 1024 13.9 k registrations/s, 4096 / 512 13.8 k, 2048 / 512 14.2-14.4 k,
@@ -145,9 +145,11 @@ __global__ __launch_bounds__(kBlock) void kd_bbox_kernel(const float4* __restric
   }
 }
 
-// key = (range number, coordinate along the range's widest axis); non-finite points go to the end of their range
-__global__ __launch_bounds__(kBlock) void kd_key_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ vals, int n, int W,
-                                                        const unsigned* __restrict__ bbox, unsigned long long* __restrict__ keys) {
+// key = (range number, coordinate along the range's widest axis) in 32 bits: the range number takes the top seg_bits, the coordinate
+// (monotone unsigned form) loses its lowest seg_bits.  The split is then at the middle rank of a slightly coarsened coordinate --
+// any split gives a correct tree, and a 32-bit sort is half the work of a 64-bit one.  Non-finite points go to the end of their range.
+__global__ __launch_bounds__(kBlock) void kd_key_kernel(const float4* __restrict__ pts, const uint32_t* __restrict__ vals, int n, int W, int seg_bits,
+                                                        const unsigned* __restrict__ bbox, uint32_t* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int seg = i / W;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void kd_key_kernel(const float4* __restrict
   const int axis = widest_axis(bb);
   const float c = axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
   const unsigned ck = finite3(p) ? orderable_f32(c) : 0xFFFFFFFFu;
-  keys[i] = ((unsigned long long)(unsigned)seg << 32) | ck;
+  keys[i] = seg_bits ? (((unsigned)seg << (32 - seg_bits)) | (ck >> seg_bits)) : ck;
 }
 
 __global__ __launch_bounds__(kBlock) void kd_clear_bbox_kernel(unsigned* __restrict__ bbox, int n_seg) {
@@ -443,11 +445,9 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64, hipStream
     int64_t W = 16;
     while (W < n) W <<= 1;
     const int max_seg = (int)std::max<int64_t>(1, (n + kKdChunk - 1) / kKdChunk);
-    DGS_HIP_TRY(h, bvh.kd_keys.reserve(n));
-    DGS_HIP_TRY(h, bvh.kd_keys_alt.reserve(n));
     DGS_HIP_TRY(h, bvh.kd_bbox.reserve((size_t)max_seg * 6 + 6));
     size_t tb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.kd_keys.ptr, bvh.kd_keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 64, st);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, bvh.keys.ptr, bvh.keys_alt.ptr, bvh.vals.ptr, bvh.vals_alt.ptr, n, 0, 32, st);
     DGS_HIP_TRY(h, h->cub_temp.reserve(tb + 256));
     uint32_t* va = bvh.vals.ptr;
     uint32_t* vb = bvh.vals_alt.ptr;
@@ -457,9 +457,9 @@ int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n64, hipStream
       int seg_bits = 0;
       while ((1 << seg_bits) < n_seg) seg_bits++;
       hipLaunchKernelGGL(kd_bbox_kernel, dim3(nb), dim3(kBlock), 0, st, pts, va, n, (int)W, bvh.kd_bbox.ptr);
-      hipLaunchKernelGGL(kd_key_kernel, dim3(nb), dim3(kBlock), 0, st, pts, va, n, (int)W, bvh.kd_bbox.ptr, bvh.kd_keys.ptr);
+      hipLaunchKernelGGL(kd_key_kernel, dim3(nb), dim3(kBlock), 0, st, pts, va, n, (int)W, seg_bits, bvh.kd_bbox.ptr, bvh.keys.ptr);
       size_t tbytes = h->cub_temp.cap;
-      DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tbytes, bvh.kd_keys.ptr, bvh.kd_keys_alt.ptr, va, vb, n, 0, 32 + seg_bits, st));
+      DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tbytes, bvh.keys.ptr, bvh.keys_alt.ptr, va, vb, n, 0, 32, st));
       std::swap(va, vb);
       const int next_seg = (int)((n + W / 2 - 1) / (W / 2));
       hipLaunchKernelGGL(kd_clear_bbox_kernel, dim3((next_seg * 6 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, bvh.kd_bbox.ptr, next_seg);
