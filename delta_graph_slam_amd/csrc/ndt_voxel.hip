@@ -93,9 +93,15 @@ int cloud_minmax(dgs_handle* h, const float4* pts, int64_t n, float out6[6]) {
 }
 
 // ---- voxel key per point (VoxelGridCovariance first pass, index arithmetic in float as upstream) ---------
+// clear_cells / clear_scalars (may be null): the dense cell table is reset to -1 and the scalar block to 0 by this same launch (grid
+// stride), instead of two fill commands in front of it
 __global__ __launch_bounds__(kBlock) void voxel_key_kernel(const float4* __restrict__ pts, int64_t n, VoxelGrid g,
-                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int* __restrict__ clear_cells,
+                                                           int64_t n_cells, int* __restrict__ clear_scalars) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (clear_cells)
+    for (int64_t c = i; c < n_cells; c += (int64_t)gridDim.x * blockDim.x) clear_cells[c] = -1;
+  if (clear_scalars && i < 8) clear_scalars[i] = 0;
   if (i >= n) return;
   const float4 p = pts[i];
   uint32_t key = 0xFFFFFFFFu;
@@ -267,10 +273,8 @@ int voxel_grid_filter(dgs_handle* h, const float4* in, int64_t n, float leaf, fl
   (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, t2, h->key_out.ptr, h->vg_run_keys.ptr, h->run_counts.ptr, h->vg_scalars.ptr, (int)n, st);
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, t3, h->run_counts.ptr, h->run_offsets.ptr, (int)n, st);
   DGS_HIP_TRY(h, h->cub_temp.reserve(std::max(t1, std::max(t2, t3)) + 256));
-  DGS_HIP_TRY(h, hipMemsetAsync(h->vg_scalars.ptr, 0, 8 * sizeof(int), st));
-  DGS_HIP_TRY(h, hipMemsetAsync(h->run_counts.ptr, 0, (size_t)n * sizeof(int), st));
   const int nb = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, in, n, g, h->key_in.ptr, h->val_in.ptr);
+  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, in, n, g, h->key_in.ptr, h->val_in.ptr, (int*)nullptr, (int64_t)0, h->vg_scalars.ptr);
   size_t tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0, 32, st));
   tb = h->cub_temp.cap;
@@ -495,11 +499,11 @@ int ndt_build_target(dgs_handle* h) {
   DGS_HIP_TRY(h, h->cub_temp.reserve(tmax + 256));
 
   // 4. keys -> stable sort -> runs -> offsets
-  DGS_HIP_TRY(h, hipMemsetAsync(h->cell2vox.ptr, 0xFF, (size_t)dense_cells * sizeof(int), st));
-  DGS_HIP_TRY(h, hipMemsetAsync(h->dev_scalars.ptr, 0, 8 * sizeof(int), st));
-  DGS_HIP_TRY(h, hipMemsetAsync(h->run_counts.ptr, 0, (size_t)n * sizeof(int), st));
+  // (the cell table and the scalar block are cleared by the key kernel itself; run_counts needs no clearing: only its first
+  // scalars[0] entries, which the run-length encoding writes, are ever read as counts)
   const int nb = (int)((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, h->tgt->pts.ptr, n, g, h->key_in.ptr, h->val_in.ptr);
+  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(kBlock), 0, st, h->tgt->pts.ptr, n, g, h->key_in.ptr, h->val_in.ptr, h->cell2vox.ptr, dense_cells,
+                     h->dev_scalars.ptr);
   size_t tb = h->cub_temp.cap;
   DGS_HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(h->cub_temp.ptr, tb, h->key_in.ptr, h->key_out.ptr, h->val_in.ptr, h->val_out.ptr, (int)n, 0,
                                                     end_bit, st));
