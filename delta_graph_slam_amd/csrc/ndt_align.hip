@@ -1108,9 +1108,14 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
 }
 
 // ================================================================================================ init / export
-__global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __restrict__ inits, int n_pairs, const NdtConsts c, int probe) {
+__global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __restrict__ inits, int n_pairs, const NdtConsts c, int probe,
+                                int* __restrict__ done_counter, const float4* const* __restrict__ stage_ptrs, const int* __restrict__ stage_sizes,
+                                const float4** __restrict__ src_ptrs, int* __restrict__ src_sizes) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 16) done_counter[i] = 0;   // the first block has 64 threads: the counter block is cleared here, not by a fill command
   if (i >= n_pairs) return;
+  src_ptrs[i] = stage_ptrs[i];
+  src_sizes[i] = stage_sizes[i];
   NdtPair* st = pairs + i;
   const NdtInit& in = inits[i];
   NdtSolver s;
@@ -1334,11 +1339,15 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
   }
   std::memcpy(base + off_ptr, src_ptrs_host, sizeof(void*) * n_pairs);
   std::memcpy(base + off_size, sizes_host, sizeof(int) * n_pairs);
-  DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, hin, sizeof(NdtInit) * n_pairs, hipMemcpyHostToDevice, st));
-  DGS_HIP_TRY(h, hipMemcpyAsync(h->src_ptrs.ptr, base + off_ptr, sizeof(void*) * n_pairs, hipMemcpyHostToDevice, st));
-  DGS_HIP_TRY(h, hipMemcpyAsync(h->src_sizes.ptr, base + off_size, sizeof(int) * n_pairs, hipMemcpyHostToDevice, st));
-  DGS_HIP_TRY(h, hipMemsetAsync(h->done_counter.ptr, 0, 16 * sizeof(int), st));
-  hipLaunchKernelGGL(ndt_init_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->pairs.ptr, h->inits.ptr, n_pairs, h->consts, probe_p6 ? 1 : 0);
+  // ONE copy of (initial poses | source pointers | sizes), contiguous in the pinned block as in the device staging buffer; the init
+  // kernel hands the pointers and sizes on to the arrays the other kernels read
+  const size_t stage_bytes = off_size + sizeof(int) * n_pairs - off_init;
+  DGS_HIP_TRY(h, h->inits.reserve((stage_bytes + sizeof(NdtInit) - 1) / sizeof(NdtInit)));
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, hin, stage_bytes, hipMemcpyHostToDevice, st));
+  const char* dstage = reinterpret_cast<const char*>(h->inits.ptr);
+  hipLaunchKernelGGL(ndt_init_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->pairs.ptr, h->inits.ptr, n_pairs, h->consts, probe_p6 ? 1 : 0,
+                     h->done_counter.ptr, reinterpret_cast<const float4* const*>(dstage + (off_ptr - off_init)),
+                     reinterpret_cast<const int*>(dstage + (off_size - off_init)), h->src_ptrs.ptr, h->src_sizes.ptr);
   return DGS_OK;
 }
 
