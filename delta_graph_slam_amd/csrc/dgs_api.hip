@@ -224,6 +224,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD")) h->nn_kd = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD_ALL")) h->nn_kd_all = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NN_KD_MIN_QUERIES")) h->nn_kd_min_queries = std::atoll(e);
   if (const char* e = std::getenv("DGS_KNN_PARTS")) { const int v = std::atoi(e); h->knn_parts = (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0; }
   if (const char* e = std::getenv("DGS_KNN_LEAF")) h->knn_leaf = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_KNN_MIN_WAVES")) h->knn_min_waves = std::max(1, std::atoi(e));
@@ -610,7 +611,9 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
   // an index built for this batch is k-d ordered: the build (a sort per level) hides behind the iterations, the fitness pass over
   // n x 65,536 queries is twice as fast as over the Hilbert order (nn_bvh.hip)
   struct KdScope { dgs_handle* h; ~KdScope() { h->batch_kd = false; } } kd_scope{h};
-  h->batch_kd = h->nn_kd && compute_fitness;
+  // ... from ~6 candidates of 65,536 points on: below that the build (~0.9 ms of side-stream time) outlasts the iterations it should hide
+  // behind (measured per tick, k-d / Hilbert: 1 candidate 0.74 / 0.59 ms, 4: 0.80 / 0.77, 8: 1.16 / 1.24, 32: 2.26 / 2.59)
+  h->batch_kd = h->nn_kd && compute_fitness && total >= h->nn_kd_min_queries;
   // The side stream forks HERE (it depends on the target only), but its launches are enqueued by ndt_align_pairs after the first
   // chunks of iteration launches: enqueueing a dozen launches costs the host ~50 us during which the main stream would sit empty.
   if (compute_fitness && (!h->tgt->bvh.valid || (h->use_grid && !h->tgt_grid.valid)) && !h->prof.enabled) {

@@ -157,6 +157,7 @@ struct dgs_handle {
   dgs::DevBuf<int> knn_nbr;           // k-NN sets of the cloud whose covariances are being made: [position in Hilbert order * 32 + slot]
   dgs::DevBuf<int> knn_stats;         // debug build (-DDGS_KNN_STATS): waves, waves on the cooperative path, candidate leaves
   bool nn_kd = true;                  // DGS_NN_KD=0: Hilbert order also for the loop batch's target index
+  int64_t nn_kd_min_queries = 6 * 65536;   // DGS_NN_KD_MIN_QUERIES: source points of a batch from which its target index is built k-d ordered
   bool nn_kd_all = false;             // DGS_NN_KD_ALL=1: every target index is k-d ordered (tests of the k-d build through the single-query hooks)
   bool batch_kd = false;              // set by dgs_align_batch* around its work: the target index it builds is k-d ordered
   int knn_parts = 0;                  // DGS_KNN_PARTS: waves per leaf in gicp_knn_leaf_kernel (0 = by cloud size)
