@@ -530,7 +530,11 @@ int dgs_nn_fitness_distances(dgs_handle* h, const float* queries, int64_t m, int
 static int gicp_batch(dgs_handle* h, int n, CloudState* const* cs, const float* guesses16, int compute_fitness, double fitness_max_range,
                       dgs_result* results) {
   struct KdScope { dgs_handle* h; ~KdScope() { h->batch_kd = false; } } kd_scope{h};
-  h->batch_kd = h->nn_kd && n >= 4;   // an index built for the target of this batch is k-d ordered
+  // an index built for the target of this batch is k-d ordered when the batch is large enough to repay the slower build, which is on the
+  // critical path here (measured per tick over resident 65,536-point keyframes, k-d / Hilbert: 4 candidates 1.38 / 1.17 ms, 8: 1.77 / 1.72,
+  // 12: 2.08 / 2.16, 32: 3.30 / 4.23)
+  static const int kd_min = std::getenv("DGS_GICP_KD_MIN_CANDIDATES") ? std::atoi(std::getenv("DGS_GICP_KD_MIN_CANDIDATES")) : 10;
+  h->batch_kd = h->nn_kd && n >= kd_min;
   int rc = gicp_align_batch(h, n, cs, guesses16, results);
   if (rc == DGS_OK && compute_fitness) {
     DGS_HIP_TRY(h, h->src_ptrs.reserve(n));
