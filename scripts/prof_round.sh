@@ -6,10 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof_$P
 cd $R
-timeout -k 10 500 python bench.py --steps 5 --warmup 2 > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_bench.err
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 > gpurun_out/${P}_bench.json 2> gpurun_out/${P}_bench.err
 echo bench-done
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$P -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-traffic > $R/gpurun_out/${P}_bench_under_rocprof.json 2> $R/gpurun_out/${P}_rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$P -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic > $R/gpurun_out/${P}_bench_under_rocprof.json 2> $R/gpurun_out/${P}_rocprof.err
 echo rocprof-done
 cd $R
 timeout -k 10 600 python scripts/bench_configs.py --frames 100 > gpurun_out/${P}_configs.jsonl 2> gpurun_out/${P}_configs.err
