@@ -212,6 +212,12 @@ def _knn_cases():
     c[:, :3] = rng.normal(size=(20000, 3)) * 0.5
     c[:200, :3] += 500.0                                   # a far cluster: window bounds of its leaves are huge
     yield "far cluster", c, 20
+    c = np.ones((3000, 4), np.float32)
+    c[:, :3] = np.float32([1.5, -2.25, 0.125])              # one point 3,000 times: every distance 0, every k-th distance a tie
+    yield "identical points", c, 20
+    c = np.ones((100, 4), np.float32)
+    c[:, :3] = rng.normal(size=(100, 3))
+    yield "k = 32 of 100", c, 32
     yield "k = 5", tgt[:30000], 5
     yield "k = 32", tgt[:30000], 32
 

@@ -387,3 +387,18 @@ def test_loop_batch_uses_the_kd_order_and_scores_like_the_hilbert_order(scans):
     for a, b in zip(out["1"], out["0"]):
         assert np.array_equal(a["T"], b["T"]) and a["converged"] == b["converged"]
         assert abs(a["fitness"] - b["fitness"]) <= 1e-12 * abs(b["fitness"])
+
+
+def test_kd_ordered_index_of_identical_points():
+    """3,000 copies of one point (every box a point, every split a tie) plus one other point: lowest index wins, the odd one is found."""
+    tgt = np.ones((3001, 4), np.float32)
+    tgt[:, :3] = np.float32([4.0, -1.0, 0.5])
+    tgt[1777, :3] = np.float32([9.0, 9.0, 9.0])
+    q = np.ones((64, 4), np.float32)
+    q[:, :3] = np.float32([4.1, -1.0, 0.5])
+    q[63, :3] = np.float32([8.0, 9.0, 9.5])
+    k = _kd_registration()
+    k.setInputTarget(tgt)
+    idx, sq = k.nearestKSearch(q)
+    assert np.all(idx[:63] == 0) and idx[63] == 1777
+    assert np.array_equal(sq, f32_sqdist(q[:, :3], tgt[idx, :3]))
