@@ -6,13 +6,15 @@
 // shipped launch file sets; object configured at src/hdl_graph_slam/registrations.cpp:27-36).  Algorithm: SURVEY.md App. B.
 //
 // MI355X design
-//   * No kd-trees: both clouds get the 8-ary Hilbert-sorted AABB index of nn_bvh.hip; k-NN covariances and the per-iteration
-//     1-NN correspondences are searched by 8-lane groups (nn_group.h), exact and bounded by max_correspondence_distance.
+//   * No pointer kd-trees: both clouds get the implicit 8-ary AABB index of nn_bvh.hip (Hilbert ordered; the target of a large
+//     batch k-d ordered).  k-NN covariances: one wave per index leaf (gicp_knn_leaf_kernel below); per-iteration 1-NN
+//     correspondences: 8-lane groups (nn_group.h), exact and bounded by max_correspondence_distance.
 //   * One linearisation = correspond (8 lanes / point) + linearize (1 lane / point, all double: RCR = C_B + R C_A R^T,
 //     3x3 inverse, J = [skew(Tp) | -I], 21 + 6 + 1 sums) with the same wave-DPP -> LDS -> fixed-order partial rows as NDT,
 //     so the sums are bit-reproducible (upstream's per-thread OpenMP partials are not).
-//   * gicp_solve (one wave per registration) runs LM / GN, se3_exp, the rho test and the convergence test on the device
-//     and queues the next evaluation in place: no host round trip per iteration.
+//   * The optimiser step (LM / GN, se3_exp, the rho test, the convergence test) runs on one wave in the LAST workgroup of a pair's
+//     linearize slice (gicp_close_round; gicp_solve_kernel is the same step as its own launch) and queues the next evaluation in
+//     place: no host round trip per iteration.
 #include <cfloat>
 #include <cmath>
 #include <cstddef>
