@@ -509,7 +509,7 @@ BvhView make_bvh_view(const Bvh& b) {
 static int ensure_target_bvh(dgs_handle* h) {
   if (side_join(h) != DGS_OK) return DGS_ERR_HIP;  // an index being built on the side stream
   if (h->tgt->bvh.valid) return DGS_OK;
-  return bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt, nullptr, h->batch_kd || h->nn_kd_all);
+  return bvh_build(h, h->tgt->bvh, h->tgt->pts.ptr, h->nt, nullptr, (h->batch_kd || h->nn_kd_all) && !h->use_grid);
 }
 
 // tree + (fitness pass) grid over the current target, on `st` (default: the handle's stream)
@@ -536,8 +536,8 @@ int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, f
 
 int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size, const float* d_T,
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
+  h->use_grid = grid_wanted(h, (int64_t)n_pairs * max_size);   // first: the grid is derived from a Hilbert ordered index
   int rc = ensure_target_bvh(h);
-  h->use_grid = grid_wanted(h, (int64_t)n_pairs * max_size);
   if (rc == DGS_OK) rc = ensure_target_index(h);
   if (rc) return rc;
   return nn_fitness_batch_on(h, h->tgt->bvh, (h->use_grid && h->tgt_grid.valid) ? &h->tgt_grid : nullptr, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, max_range,
