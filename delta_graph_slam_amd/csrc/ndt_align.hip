@@ -641,19 +641,6 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_derivatives_strict_kernel(const
   }
 }
 
-// ndt_strict_order 1: block rows -> totals, one wave per pair, rows added in slice order
-__global__ __launch_bounds__(kWave) void ndt_strict_reduce_kernel(const NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
-                                                                  const int* __restrict__ pair_blocks, double* __restrict__ totals) {
-  const int pair = blockIdx.x;
-  if (!pairs[pair].active) return;
-  const int nb = pair_blocks[pair];
-  if (threadIdx.x >= kStrictPad) return;
-  double v = 0.0;
-  const double* base = partials + (size_t)pair * cap_blocks * kStrictPad;
-  for (int b = 0; b < nb; b++) v += base[(size_t)b * kStrictPad + threadIdx.x];
-  totals[(size_t)pair * kStrictPad + threadIdx.x] = v;
-}
-
 // ndt_strict_order 2: upstream's final loop -- score / gradient / Hessian entries summed over the points in index order, one
 // lane per entry (a dependent chain of n double additions: this mode exists to prove bit-parity, not to be fast)
 __global__ __launch_bounds__(kWave) void ndt_strict_seqsum_kernel(const NdtPair* __restrict__ pairs, const int* __restrict__ src_sizes,
@@ -1069,7 +1056,7 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
 
 __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
                                                            const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter,
-                                                           const double* __restrict__ strict_totals) {
+                                                           const double* __restrict__ strict_totals, const int strict_from_rows) {
   const int pair = blockIdx.x;
   NdtPair* st = pairs + pair;
   if (!st->active) return;
@@ -1086,7 +1073,26 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
     s_lds = st->s;
     need_h = st->need_hessian;
   }
-  if (threadIdx.x < kStrictPad) tot[threadIdx.x] = strict_totals[(size_t)pair * kStrictPad + threadIdx.x];
+  if (threadIdx.x < kStrictPad) {
+    if (strict_from_rows) {
+      // order 1: the workgroups' rows added in slice order (what ndt_strict_reduce_kernel did as a launch of its own), four loads in
+      // flight, the additions in the same sequence
+      const int nb = pair_blocks[pair];
+      const double* base = partials + (size_t)pair * cap_blocks * kStrictPad + threadIdx.x;
+      double v = 0.0;
+      for (int b0 = 0; b0 < nb; b0 += 4) {
+        double r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = base[(size_t)min(b0 + k, nb - 1) * kStrictPad];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (b0 + k < nb) v += r[k];
+      }
+      tot[threadIdx.x] = v;
+    } else {
+      tot[threadIdx.x] = strict_totals[(size_t)pair * kStrictPad + threadIdx.x];
+    }
+  }
   __syncthreads();
   if (threadIdx.x >= kWave) return;
   const bool writer = threadIdx.x == 0;
@@ -1246,9 +1252,7 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
     if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL)
       hipLaunchKernelGGL(ndt_strict_seqsum_kernel, dim3(L.n_pairs), dim3(kWave), 0, h->stream, h->pairs.ptr, h->src_sizes.ptr, h->strict_rows.ptr, L.max_n,
                          h->strict_totals.ptr);
-    else
-      hipLaunchKernelGGL(ndt_strict_reduce_kernel, dim3(L.n_pairs), dim3(kWave), 0, h->stream, h->pairs.ptr, h->partials.ptr, L.cap_blocks, h->pair_blocks.ptr,
-                         h->strict_totals.ptr);
+    // (order 1: the rows are summed by ndt_solve_kernel itself)
     prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
     return;
   }
@@ -1283,7 +1287,8 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
 static void launch_solve(dgs_handle* h, const NdtLaunch& L) {
   int slot = prof_begin(h, DGS_K_NDT_SOLVE);
   hipLaunchKernelGGL(ndt_solve_kernel, dim3(L.n_pairs), dim3(kBlock), 0, h->stream, h->pairs.ptr, h->partials.ptr, L.cap_blocks, h->pair_blocks.ptr, h->consts,
-                     h->done_counter.ptr, h->consts.strict_order != DGS_NDT_ORDER_FAST ? h->strict_totals.ptr : nullptr);
+                     h->done_counter.ptr, h->consts.strict_order != DGS_NDT_ORDER_FAST ? h->strict_totals.ptr : nullptr,
+                     h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM ? 1 : 0);
   prof_end(h, DGS_K_NDT_SOLVE, slot);
 }
 
