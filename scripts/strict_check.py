@@ -24,8 +24,9 @@ def main():
     ap.add_argument("--points", type=int, default=65536)
     ap.add_argument("--eps", type=float, default=0.01)
     ap.add_argument("--distinct-scans", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=40, help="40 = the bench workload of rank 0; 1040, 2040, ... = the other ranks' shards")
     a = ap.parse_args()
-    tgt, sources, guesses, gts = synth.loop_batch(n_candidates=a.pairs, n_points=a.points, seed=40, distinct_scans=min(a.distinct_scans, a.pairs))
+    tgt, sources, guesses, gts = synth.loop_batch(n_candidates=a.pairs, n_points=a.points, seed=a.seed, distinct_scans=min(a.distinct_scans, a.pairs))
     o = orc.NdtOracle(resolution=1.0, transformation_epsilon=a.eps)
     o.set_target(tgt)
     vo = o.voxels()
