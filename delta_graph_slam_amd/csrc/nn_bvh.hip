@@ -550,7 +550,8 @@ int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pai
   const BvhView v = make_bvh_view(index);
   // tree walk: one query per 8 lanes; grid: one query per lane
   const int full = std::max(1, (int)(((int64_t)max_size * (grid ? 1 : 8) + kBlock - 1) / kBlock));
-  const int bpp = std::max(1, std::min(full, std::max(64, 8192 / std::max(1, n_pairs))));
+  static const int total_blocks = std::getenv("DGS_NN_BLOCKS") ? std::atoi(std::getenv("DGS_NN_BLOCKS")) : 8192;   // launch-shape sweeps
+  const int bpp = std::max(1, std::min(full, std::max(64, total_blocks / std::max(1, n_pairs))));
   DGS_HIP_TRY(h, h->nn_partials.reserve((size_t)n_pairs * bpp * 4 + (size_t)n_pairs * 4));
   double* d_out = h->nn_partials.ptr + (size_t)n_pairs * bpp * 4;
   if (ensure_pinned(h, 4096 + sizeof(double) * 4 * n_pairs) != DGS_OK) return DGS_ERR_HIP;
