@@ -1,5 +1,6 @@
 # SQ / cache counters per kernel for the bench workload: separate rocprofv3 --pmc passes (--kernel-trace only, as the pool requires),
-# summarised by scripts/pmc_summarise.py.  usage on the GPU box (repo root): bash scripts/pmc_round.sh <prefix>
+# summarised by scripts/pmc_summarise.py.  usage on the GPU box (repo root): bash scripts/pmc_round.sh <prefix> [script args...]
+# (default workload: bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic; PMC_CMD="scripts/dbg_strict_profile.py" profiles another script)
 set -e
 P=${1:-x}
 cd /tmp && export TMPDIR=/tmp
@@ -12,7 +13,7 @@ for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCL
            "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
   if [ -n "$NPASS" ] && [ $i -gt $NPASS ]; then break; fi
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic > $OUT/pass$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pass$i -- python3 $R/${PMC_CMD:-bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic} > $OUT/pass$i.log 2>&1
   echo "pass $i done: $SET"
 done
 cd $R
