@@ -87,7 +87,7 @@ __device__ __forceinline__ v2f affine_row_rn2(float m0, float m1, float m2, floa
 // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two points per instruction); look-ups, the double q = x' - mean, exp and the
 // double accumulation stay per point.  The per-thread order of accumulation is unchanged (i, i + stride, i + 2 stride, ...).
 template <int SEARCH, bool FUSED, bool PACK2>
-__global__ __launch_bounds__(kBlock, 4) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
+__global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
                                                                     NdtPair* __restrict__ pairs, const VoxelGrid g, const double gd1,
                                                                     const float gd2, const int leaf_pow2, double* __restrict__ partials,
                                                                     const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks,
