@@ -55,21 +55,25 @@ SYMBOLS = [
     "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize", "dgs_vgicp_get_voxels",
     "dgs_group_create", "dgs_group_destroy", "dgs_group_last_error", "dgs_group_size", "dgs_group_uses_rccl", "dgs_group_last_gather_used_rccl",
     "dgs_group_member", "dgs_group_set_input_target", "dgs_group_align_batch",
+    "dgs_group_cloud_create", "dgs_group_cloud_destroy", "dgs_group_cloud_size", "dgs_group_cloud_copies", "dgs_group_set_input_target_cloud",
+    "dgs_group_align_batch_clouds",
 ]
 
-_lib = None
+_libs = {}
+EXPERIMENTS_LIB_PATH = os.path.join(_HERE, "libdgs_reg_exp.so")   # `make experiments`: + nn_grid.hip and the packed-FP32 kernel (measured losers)
 
 
-def load():
-    """Load libdgs_reg.so.  Raises ImportError (never falls back) when it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load libdgs_reg.so (or another build of it, e.g. EXPERIMENTS_LIB_PATH).  Raises ImportError (never falls back) when it has
+    not been built."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C delta_graph_slam_amd/csrc).  delta_graph_slam_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P = C.POINTER
     lib.dgs_last_error.restype = C.c_char_p
     lib.dgs_last_error.argtypes = [C.c_void_p]
@@ -122,5 +126,14 @@ def load():
     lib.dgs_group_set_input_target.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.dgs_group_align_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, P(Result), P(C.c_int32),
                                           P(C.c_double)]
-    _lib = lib
+    lib.dgs_group_cloud_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, P(C.c_void_p)]
+    lib.dgs_group_cloud_destroy.argtypes = [C.c_void_p]
+    lib.dgs_group_cloud_destroy.restype = None
+    lib.dgs_group_cloud_size.argtypes = [C.c_void_p]
+    lib.dgs_group_cloud_size.restype = C.c_int64
+    lib.dgs_group_cloud_copies.argtypes = [C.c_void_p]
+    lib.dgs_group_set_input_target_cloud.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dgs_group_align_batch_clouds.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, P(Result), P(C.c_int32),
+                                                 P(C.c_double)]
+    _libs[path] = lib
     return lib

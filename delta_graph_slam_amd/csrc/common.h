@@ -191,6 +191,41 @@ __device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, P
 }
 #endif
 
+// ---- in-launch hand-off of partial rows to a pair's closing workgroup (fused NDT / GICP launches) ------------------------------------
+// Default = the WRITE-THROUGH form of the agent-scope recipe: every byte of a row is stored with an agent-scope atomic store
+// (sc1: written through to memory, never left dirty in this XCD's L2), the storing wave drains its stores (s_waitcnt vmcnt(0)), a
+// workgroup barrier, then ONE lane takes the pair's ticket with an agent-scope atomic add; the workgroup whose add came last reads
+// the rows with agent-scope atomic loads (sc1: never served from a line this XCD cached earlier).  Coherence is per access, so no
+// cache-wide write-back / invalidate is paid.  tests/test_isa_handoff.py checks that the compiled kernels contain exactly this
+// sequence (sc1 stores, the drain, the barrier before the atomic, sc1 loads behind it), so a compiler change cannot silently
+// reorder it.  -DDGS_HANDOFF_FENCES (`make fences`) builds the textbook form instead -- plain row stores / loads, the ticket an
+// acq_rel RMW, i.e. buffer_wbl2 + buffer_inv around it -- for A/B runs (bit-equal results, slower: DESIGN.md).
+#ifdef __HIPCC__
+#ifdef DGS_HANDOFF_FENCES
+constexpr bool kHandoffFences = true;
+#else
+constexpr bool kHandoffFences = false;
+#endif
+__device__ __forceinline__ void handoff_store_row(double* p, double v) {
+  if (kHandoffFences) *p = v;
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void handoff_drain_stores() {   // by the storing wave, before the workgroup barrier in front of the ticket
+  if (!kHandoffFences) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ double handoff_load_row(const double* p) {
+  return kHandoffFences ? *p : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one lane per workgroup, behind a workgroup barrier; true for the workgroup that took the pair's last ticket of this launch
+__device__ __forceinline__ bool handoff_take_ticket(int* ticket, int n_slices) {
+  const int t = kHandoffFences ? __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                               : __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool last = t == n_slices - 1;
+  if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch (ordered by the kernel boundary)
+  return last;
+}
+#endif
+
 // ---- error handling --------------------------------------------------------------------------------------
 #define DGS_HIP_TRY(h, expr)                                                                      \
   do {                                                                                            \

@@ -159,6 +159,34 @@ static void bind(dgs_handle* h, dgs_cloud*& slot, dgs_cloud* c) {
   slot = c;
 }
 
+namespace dgs {
+int cloud_clone_to(dgs_handle* h, const dgs_cloud* src, dgs_cloud** out) {
+  *out = nullptr;
+  DGS_HIP_TRY(h, hipSetDevice(h->device));
+  dgs_cloud* c = new (std::nothrow) dgs_cloud();
+  if (!c) return DGS_ERR_HIP;
+  c->device = h->device;
+  c->st.n = src->st.n;
+  hipError_t e = hipSuccess;
+  if (src->st.n > 0) {
+    e = c->st.pts.reserve((size_t)src->st.n);
+    const size_t bytes = (size_t)src->st.n * sizeof(float4);
+    if (e == hipSuccess)
+      e = (src->device == h->device) ? hipMemcpyAsync(c->st.pts.ptr, src->st.pts.ptr, bytes, hipMemcpyDeviceToDevice, h->stream)
+                                     : hipMemcpyPeerAsync(c->st.pts.ptr, h->device, src->st.pts.ptr, src->device, bytes, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
+  if (e != hipSuccess) {
+    h->err = std::string("cloud_clone_to: ") + hipGetErrorString(e);
+    c->st.release();
+    delete c;
+    return DGS_ERR_HIP;
+  }
+  *out = c;
+  return DGS_OK;
+}
+}  // namespace dgs
+
 static thread_local std::string g_create_error;  // dgs_last_error(NULL): why the last dgs_create on this thread failed
 
 extern "C" {
@@ -220,7 +248,8 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   }
   h->device = dev;
   h->own_stream = true;
-  if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
+  if (kExperiments)   // the product library carries neither the grid index nor the packed-FP32 kernel (measured losers: `make experiments`)
+    if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD")) h->nn_kd = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD_ALL")) h->nn_kd_all = std::atoi(e) != 0;
@@ -230,7 +259,8 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (const char* e = std::getenv("DGS_KNN_MIN_WAVES")) h->knn_min_waves = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DGS_KNN_ROUNDS")) h->knn_rounds = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DGS_GICP_FUSED")) h->gicp_fused = std::atoi(e) != 0;
-  if (const char* e = std::getenv("DGS_NDT_PACK2")) h->ndt_pack2 = std::atoi(e) != 0;
+  if (kExperiments)
+    if (const char* e = std::getenv("DGS_NDT_PACK2")) h->ndt_pack2 = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_GRID_FACTOR")) h->grid_spacing_factor = std::max(0.5f, (float)std::atof(e));
   std::memset(h->final_T, 0, sizeof(h->final_T));
   h->final_T[0] = h->final_T[5] = h->final_T[10] = h->final_T[15] = 1.f;

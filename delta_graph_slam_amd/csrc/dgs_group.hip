@@ -128,34 +128,53 @@ struct dgs_group {
   Rccl rccl;
   std::vector<void*> comms;          // one ncclComm_t per member (empty: host gather)
   std::vector<void*> d_send, d_recv; // per member: its records / everybody's records
+  std::vector<void*> d_stage;        // per member: {candidate numbers | guesses} of its share, uploaded BEFORE its batch starts
   std::vector<void*> h_stage;        // pinned staging per member
   size_t cap_per_member = 0;         // records each member's buffers hold
   bool used_rccl = false;
   std::string err;
 };
 
+// KeyFrame::cloud (keyframe.hpp:51: set once, never written again) resident on the group's devices: one dgs_cloud per member
+// that holds a copy.  Outlives any number of ticks; may outlive the group (the copies are plain dgs_cloud objects).
+struct dgs_group_cloud {
+  std::vector<dgs_cloud*> copy;      // [member] or nullptr
+  int64_t n = 0;
+};
+
 namespace {
+
+// keeps the CALLER's current HIP device what it was: the group's functions visit every member's device on the caller's thread
+struct DeviceScope {
+  int prev = -1;
+  DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 void free_buffers(dgs_group* g) {
   for (size_t k = 0; k < g->members.size(); k++) {
     (void)hipSetDevice(g->devices[k]);
     if (k < g->d_send.size() && g->d_send[k]) (void)hipFree(g->d_send[k]);
     if (k < g->d_recv.size() && g->d_recv[k]) (void)hipFree(g->d_recv[k]);
+    if (k < g->d_stage.size() && g->d_stage[k]) (void)hipFree(g->d_stage[k]);
     if (k < g->h_stage.size() && g->h_stage[k]) (void)hipHostFree(g->h_stage[k]);
   }
-  g->d_send.clear(); g->d_recv.clear(); g->h_stage.clear();
+  g->d_send.clear(); g->d_recv.clear(); g->d_stage.clear(); g->h_stage.clear();
   g->cap_per_member = 0;
 }
+
+constexpr size_t kStageBytes = 4 + 64;   // per candidate: its number in the caller's list, its guess (16 floats)
 
 bool ensure_buffers(dgs_group* g, size_t per_member) {
   if (per_member <= g->cap_per_member) return true;
   free_buffers(g);
   const size_t G = g->members.size();
-  g->d_send.assign(G, nullptr); g->d_recv.assign(G, nullptr); g->h_stage.assign(G, nullptr);
+  g->d_send.assign(G, nullptr); g->d_recv.assign(G, nullptr); g->d_stage.assign(G, nullptr); g->h_stage.assign(G, nullptr);
   const size_t want = per_member + per_member / 2 + 8;
   for (size_t k = 0; k < G; k++) {
     if (hipSetDevice(g->devices[k]) != hipSuccess || hipMalloc(&g->d_send[k], want * kRecordBytes) != hipSuccess ||
-        hipMalloc(&g->d_recv[k], want * kRecordBytes * G) != hipSuccess || hipHostMalloc(&g->h_stage[k], want * kRecordBytes * G, hipHostMallocDefault) != hipSuccess) {
+        hipMalloc(&g->d_recv[k], want * kRecordBytes * G) != hipSuccess || hipMalloc(&g->d_stage[k], want * kStageBytes) != hipSuccess ||
+        hipHostMalloc(&g->h_stage[k], std::max(want * kRecordBytes * G, want * kStageBytes), hipHostMallocDefault) != hipSuccess) {
       g->err = "dgs_group: buffer allocation failed";
       free_buffers(g);
       return false;
@@ -165,6 +184,194 @@ bool ensure_buffers(dgs_group* g, size_t per_member) {
   return true;
 }
 
+// One thread per candidate of a member's share: the exchange record, written ON THE DEVICE from the optimiser state and the
+// fitness sums the member's kernels left in HBM -- what loop_detector.hpp:145-155 reads per candidate.  Mirrors what
+// dgs_align_batch reports on the host bit for bit (fitness = sum / count in double, DBL_MAX without a qualifying point; an empty
+// source is "not converged, transformation = guess", scan_matching_odometry_nodelet.cpp:222-226).
+__global__ void group_record_kernel(const int method, const dgs::NdtPair* __restrict__ npairs, const int* __restrict__ nsizes,
+                                    const dgs::GicpPair* __restrict__ gpairs, const dgs::GicpItem* __restrict__ gitems,
+                                    const double* __restrict__ nn_out, const int compute_fitness, const int* __restrict__ cand,
+                                    const float* __restrict__ guesses, const int m, char* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Record r;
+  r.pad = 0;
+  r.candidate = cand[i];
+  r.status = DGS_OK;
+  const float* Tsrc;
+  int size;
+  if (method == DGS_METHOD_NDT) {
+    const dgs::NdtPair& p = npairs[i];
+    size = nsizes[i];
+    Tsrc = p.final_T;
+    r.converged = (p.s.phase == dgs::PH_DONE) ? p.s.converged : 0;
+    r.iterations = p.s.nr_iterations;
+    r.evaluations = p.s.evaluations;
+    r.score = p.s.score;
+  } else {
+    const dgs::GicpPair& p = gpairs[i];
+    size = gitems[i].n;
+    Tsrc = p.final_T;
+    r.converged = (p.s.phase == dgs::GP_DONE) ? p.s.converged : 0;
+    r.iterations = p.s.iteration;
+    r.evaluations = p.s.evaluations;
+    r.score = p.s.y0;
+  }
+  r.fitness = __builtin_nan("");
+  if (compute_fitness) {
+    const double sum = nn_out[i * 4 + 0], cnt = nn_out[i * 4 + 1];
+    r.fitness = cnt > 0 ? sum / cnt : DBL_MAX;
+  }
+  if (size <= 0) {   // PCL refuses an empty source: not converged, transform = guess
+    Tsrc = guesses + 16 * (size_t)i;
+    r.converged = 0; r.iterations = 0; r.evaluations = 0; r.status = DGS_ERR_NO_SOURCE;
+    r.score = 0.0; r.fitness = __builtin_nan("");
+  }
+  for (int k = 0; k < 16; k++) r.T[k] = Tsrc[k];
+  *reinterpret_cast<Record*>(out + (size_t)i * kRecordBytes) = r;
+}
+
+// Runs on member k's worker thread right after its batch: staging (candidate numbers, guesses) up, records written by the device
+// into d_send[k] on the member's stream.  Nothing the all-gather sends has been on the host.
+bool enqueue_records(dgs_group* g, int k, const std::vector<int>& ids, const float* guesses_of_member, int per, int compute_fitness) {
+  dgs_handle* h = g->members[k];
+  const int m = (int)ids.size();
+  if (hipSetDevice(g->devices[k]) != hipSuccess) return false;
+  if (hipMemsetAsync(g->d_send[k], 0xFF, (size_t)per * kRecordBytes, h->stream) != hipSuccess) return false;   // candidate = -1: padding rows
+  if (m == 0) return true;
+  char* hs = static_cast<char*>(g->h_stage[k]);
+  std::memcpy(hs, ids.data(), sizeof(int) * m);
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float* hg = reinterpret_cast<float*>(hs + sizeof(int) * (size_t)per);
+  for (int j = 0; j < m; j++) std::memcpy(hg + 16 * (size_t)j, guesses_of_member ? guesses_of_member + 16 * (size_t)j : ident, sizeof(float) * 16);
+  if (hipMemcpyAsync(g->d_stage[k], hs, sizeof(int) * (size_t)per + 64 * (size_t)m, hipMemcpyHostToDevice, h->stream) != hipSuccess) return false;
+  const char* ds = static_cast<const char*>(g->d_stage[k]);
+  const bool ndt = h->prm.method == DGS_METHOD_NDT;
+  hipLaunchKernelGGL(group_record_kernel, dim3((m + 63) / 64), dim3(64), 0, h->stream, (int)h->prm.method, ndt ? h->pairs.ptr : nullptr,
+                     ndt ? h->src_sizes.ptr : nullptr, ndt ? nullptr : h->gpairs.ptr, ndt ? nullptr : h->gitems.ptr, h->nn_out, compute_fitness,
+                     reinterpret_cast<const int*>(ds), reinterpret_cast<const float*>(ds + sizeof(int) * (size_t)per), m, static_cast<char*>(g->d_send[k]));
+  return hipGetLastError() == hipSuccess;
+}
+
+void fail_share(std::vector<dgs_result>& res, const float* gs, int rc) {
+  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  for (size_t j = 0; j < res.size(); j++) {
+    std::memcpy(res[j].final_transformation, gs ? gs + 16 * j : ident, sizeof(float) * 16);
+    res[j].converged = 0; res[j].iterations = 0; res[j].evaluations = 0; res[j].status = rc;
+    res[j].score = 0.0; res[j].fitness = NAN;
+  }
+}
+
+// The dealt batch: `ids[k]` = the candidates of member k in the order it registers them; `run(k, results_of_member)` registers them.
+int run_dealt_batch(dgs_group* g, int n, const std::vector<std::vector<int>>& ids, const float* guesses16, int32_t compute_fitness,
+                    const std::function<int(int, const float*, dgs_result*)>& run, dgs_result* results, int32_t* best_index, double* best_score) {
+  const int G = (int)g->members.size();
+  int per = 1;
+  for (int k = 0; k < G; k++) per = std::max(per, (int)ids[k].size());
+  std::vector<std::vector<float>> gs(G);
+  std::vector<std::vector<dgs_result>> res(G);
+  std::vector<int> rcs(G, DGS_OK);
+  std::vector<char> dev_ok(G, 0);
+  for (int k = 0; k < G; k++) {
+    res[k].resize(ids[k].size());
+    if (guesses16)
+      for (int c : ids[k]) gs[k].insert(gs[k].end(), guesses16 + 16 * (size_t)c, guesses16 + 16 * (size_t)c + 16);
+  }
+  const bool have_buffers = ensure_buffers(g, (size_t)per);
+  // ---- every member registers its share as one batch on its own thread / stream, then writes its records on the device
+  for (int k = 0; k < G; k++) {
+    auto job = [g, k, per, have_buffers, compute_fitness, guesses16, &ids, &gs, &res, &rcs, &dev_ok, &run] {
+      const float* gk = guesses16 ? gs[k].data() : nullptr;
+      if (!ids[k].empty()) rcs[k] = run(k, gk, res[k].data());
+      if (rcs[k] != DGS_OK) fail_share(res[k], gk, rcs[k]);   // reported per candidate as "not converged" (the reference skips them, loop_detector.hpp:149)
+      if (have_buffers && rcs[k] == DGS_OK) dev_ok[k] = enqueue_records(g, k, ids[k], gk, per, compute_fitness) ? 1 : 0;
+    };
+    if (g->workers[k]) g->workers[k]->submit(job); else job();
+  }
+  for (int k = 0; k < G; k++)
+    if (g->workers[k]) g->workers[k]->wait();
+  for (int k = 0; k < G; k++)
+    if (rcs[k] != DGS_OK) g->err = "member " + std::to_string(k) + " (device " + std::to_string(g->devices[k]) + "): " + dgs_last_error(g->members[k]);
+  // a member whose batch (or record launch) failed sends host-made records instead: the collective still needs its contribution
+  std::vector<Record> all((size_t)G * per);
+  for (auto& r : all) { std::memset(&r, 0, sizeof(r)); r.candidate = -1; }
+  auto fill_host = [&](int k, Record* dst) {
+    for (size_t j = 0; j < res[k].size(); j++) {
+      Record& r = dst[j];
+      const dgs_result& a = res[k][j];
+      r.fitness = a.fitness; r.score = a.score;
+      std::memcpy(r.T, a.final_transformation, sizeof(r.T));
+      r.candidate = ids[k][j];
+      r.converged = a.converged; r.iterations = a.iterations; r.evaluations = a.evaluations; r.status = a.status;
+    }
+  };
+  bool ok = have_buffers;
+  for (int k = 0; k < G && ok; k++) {
+    if (dev_ok[k]) continue;
+    char* hs = static_cast<char*>(g->h_stage[k]);
+    std::vector<Record> mine(per);
+    for (auto& r : mine) { std::memset(&r, 0, sizeof(r)); r.candidate = -1; }
+    fill_host(k, mine.data());
+    std::memset(hs, 0, (size_t)per * kRecordBytes);
+    for (int j = 0; j < per; j++) std::memcpy(hs + (size_t)j * kRecordBytes, &mine[j], sizeof(Record));
+    ok = hipSetDevice(g->devices[k]) == hipSuccess &&
+         hipMemcpyAsync(g->d_send[k], hs, (size_t)per * kRecordBytes, hipMemcpyHostToDevice, g->members[k]->stream) == hipSuccess;
+  }
+  // ---- the exchange step: fixed-size records, all-gathered over RCCL (xGMI) when the group has communicators; the members' streams
+  // carry it right behind their record kernels
+  bool gathered = false;
+  if (ok && !g->comms.empty()) {
+    ok = g->rccl.GroupStart() == 0;
+    for (int k = 0; k < G && ok; k++)
+      ok = g->rccl.AllGather(g->d_send[k], g->d_recv[k], (size_t)per * kRecordBytes, kNcclUint8, g->comms[k], g->members[k]->stream) == 0;
+    ok = (g->rccl.GroupEnd() == 0) && ok;
+    if (ok) {   // member 0 holds everybody's records after the collective: one device->host copy
+      char* hs = static_cast<char*>(g->h_stage[0]);
+      ok = hipSetDevice(g->devices[0]) == hipSuccess &&
+           hipMemcpyAsync(hs, g->d_recv[0], (size_t)G * per * kRecordBytes, hipMemcpyDeviceToHost, g->members[0]->stream) == hipSuccess;
+      for (int k = 0; k < G && ok; k++) ok = hipSetDevice(g->devices[k]) == hipSuccess && hipStreamSynchronize(g->members[k]->stream) == hipSuccess;
+      if (ok) {
+        for (size_t j = 0; j < (size_t)G * per; j++) std::memcpy(&all[j], hs + j * kRecordBytes, sizeof(Record));
+        gathered = true;
+        g->used_rccl = true;
+      }
+    }
+    if (!ok) g->err = "dgs_group: RCCL all-gather failed, gathered on the host instead";
+  } else if (ok) {
+    // no communicators (a device listed twice, or no RCCL): every member's device-written records come to the host directly
+    for (int k = 0; k < G && ok; k++)
+      ok = hipSetDevice(g->devices[k]) == hipSuccess &&
+           hipMemcpyAsync(g->h_stage[k], g->d_send[k], (size_t)per * kRecordBytes, hipMemcpyDeviceToHost, g->members[k]->stream) == hipSuccess;
+    for (int k = 0; k < G && ok; k++) ok = hipSetDevice(g->devices[k]) == hipSuccess && hipStreamSynchronize(g->members[k]->stream) == hipSuccess;
+    if (ok) {
+      for (int k = 0; k < G; k++)
+        for (int j = 0; j < per; j++) std::memcpy(&all[(size_t)k * per + j], static_cast<char*>(g->h_stage[k]) + (size_t)j * kRecordBytes, sizeof(Record));
+      gathered = true;
+    }
+  }
+  if (!gathered)   // last resort (allocation / copy failure): the members' host-side results
+    for (int k = 0; k < G; k++) fill_host(k, all.data() + (size_t)k * per);
+  // ---- results back in ORIGINAL candidate order, then the arg-min of loop_detector.hpp:126-156
+  for (const Record& r : all) {
+    if (r.candidate < 0 || r.candidate >= n) continue;
+    dgs_result& o = results[r.candidate];
+    std::memcpy(o.final_transformation, r.T, sizeof(r.T));
+    o.converged = r.converged; o.iterations = r.iterations; o.evaluations = r.evaluations; o.status = r.status;
+    o.score = r.score; o.fitness = r.fitness;
+  }
+  double best = DBL_MAX;
+  int bi = -1;
+  if (compute_fitness)
+    for (int c = 0; c < n; c++) {
+      if (!results[c].converged || results[c].fitness > best || results[c].fitness != results[c].fitness) continue;   // "score > best_score" skips; ties: the later wins
+      best = results[c].fitness;
+      bi = c;
+    }
+  if (best_index) *best_index = bi;
+  if (best_score) *best_score = best;
+  return DGS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -172,6 +379,7 @@ extern "C" {
 int dgs_group_create(const dgs_params* params, const int32_t* devices, int32_t n_devices, dgs_group** out) {
   if (!params || !out || !devices || n_devices < 1 || n_devices > 64) return DGS_ERR_INVALID_ARGUMENT;
   *out = nullptr;
+  DeviceScope keep;
   dgs_group* g = new (std::nothrow) dgs_group();
   if (!g) return DGS_ERR_HIP;
   int rc = DGS_OK;
@@ -214,6 +422,7 @@ int dgs_group_create(const dgs_params* params, const int32_t* devices, int32_t n
 
 void dgs_group_destroy(dgs_group* g) {
   if (!g) return;
+  DeviceScope keep;
   for (Worker* w : g->workers)
     if (w) { w->shutdown(); delete w; }
   for (size_t k = 0; k < g->comms.size(); k++)
@@ -229,14 +438,14 @@ int32_t dgs_group_size(const dgs_group* g) { return g ? (int32_t)g->members.size
 int32_t dgs_group_uses_rccl(const dgs_group* g) { return (g && !g->comms.empty()) ? 1 : 0; }
 dgs_handle* dgs_group_member(dgs_group* g, int32_t k) { return (g && k >= 0 && (size_t)k < g->members.size()) ? g->members[k] : nullptr; }
 
-int dgs_group_set_input_target(dgs_group* g, const float* xyz16, int64_t n) {
-  if (!g || n < 0 || (n > 0 && !xyz16)) return DGS_ERR_INVALID_ARGUMENT;
-  g->err.clear();
+// runs job(k) for every member on its worker thread and waits; returns the first failing member's status
+static int for_each_member(dgs_group* g, const std::function<int(int)>& job, const std::function<bool(int)>& wanted = nullptr) {
   const size_t G = g->members.size();
   std::vector<int> rcs(G, DGS_OK);
   for (size_t k = 0; k < G; k++) {
-    auto job = [g, k, xyz16, n, &rcs] { rcs[k] = dgs_set_input_target(g->members[k], xyz16, n, 0); };
-    if (g->workers[k]) g->workers[k]->submit(job); else job();
+    if (wanted && !wanted((int)k)) continue;
+    auto j = [&rcs, &job, k] { rcs[k] = job((int)k); };
+    if (g->workers[k]) g->workers[k]->submit(j); else j();
   }
   for (size_t k = 0; k < G; k++)
     if (g->workers[k]) g->workers[k]->wait();
@@ -248,6 +457,13 @@ int dgs_group_set_input_target(dgs_group* g, const float* xyz16, int64_t n) {
   return DGS_OK;
 }
 
+int dgs_group_set_input_target(dgs_group* g, const float* xyz16, int64_t n) {
+  if (!g || n < 0 || (n > 0 && !xyz16)) return DGS_ERR_INVALID_ARGUMENT;
+  g->err.clear();
+  DeviceScope keep;
+  return for_each_member(g, [g, xyz16, n](int k) { return dgs_set_input_target(g->members[k], xyz16, n, 0); });
+}
+
 int dgs_group_align_batch(dgs_group* g, int32_t n, const float* const* sources, const int64_t* sizes, const float* guesses16, int32_t compute_fitness,
                           double fitness_max_range, dgs_result* results, int32_t* best_index, double* best_score) {
   if (!g || n < 0 || (n > 0 && (!sources || !sizes || !results))) return DGS_ERR_INVALID_ARGUMENT;
@@ -256,109 +472,110 @@ int dgs_group_align_batch(dgs_group* g, int32_t n, const float* const* sources, 
   if (best_index) *best_index = -1;
   if (best_score) *best_score = DBL_MAX;
   if (n == 0) return DGS_OK;
+  DeviceScope keep;
   const int G = (int)g->members.size();
-  const int per = (n + G - 1) / G;
-  // ---- deal: candidate c -> member c mod G; every member registers its share as one batch on its own thread / stream
+  // ---- deal: candidate c -> member c mod G
+  std::vector<std::vector<int>> ids(G);
   std::vector<std::vector<const float*>> src(G);
   std::vector<std::vector<int64_t>> sz(G);
-  std::vector<std::vector<float>> gs(G);
-  std::vector<std::vector<dgs_result>> res(G);
-  std::vector<int> rcs(G, DGS_OK);
   for (int c = 0; c < n; c++) {
-    const int k = c % G;
-    src[k].push_back(sources[c]);
-    sz[k].push_back(sizes[c]);
-    if (guesses16) gs[k].insert(gs[k].end(), guesses16 + 16 * (size_t)c, guesses16 + 16 * (size_t)c + 16);
+    ids[c % G].push_back(c);
+    src[c % G].push_back(sources[c]);
+    sz[c % G].push_back(sizes[c]);
   }
-  for (int k = 0; k < G; k++) {
-    res[k].resize(src[k].size());
-    auto job = [g, k, &src, &sz, &gs, &res, &rcs, guesses16, compute_fitness, fitness_max_range] {
-      if (src[k].empty()) return;
-      rcs[k] = dgs_align_batch(g->members[k], (int32_t)src[k].size(), src[k].data(), sz[k].data(), 0, guesses16 ? gs[k].data() : nullptr, compute_fitness,
-                               fitness_max_range, res[k].data());
-    };
-    if (g->workers[k]) g->workers[k]->submit(job); else job();
-  }
-  for (int k = 0; k < G; k++)
-    if (g->workers[k]) g->workers[k]->wait();
-  // a member that failed as a whole reports its candidates as not converged (the reference skips them, loop_detector.hpp:149)
-  for (int k = 0; k < G; k++)
-    if (rcs[k] != DGS_OK) {
-      g->err = "member " + std::to_string(k) + " (device " + std::to_string(g->devices[k]) + "): " + dgs_last_error(g->members[k]);
-      for (size_t j = 0; j < res[k].size(); j++) {
-        const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        std::memcpy(res[k][j].final_transformation, guesses16 ? gs[k].data() + 16 * j : ident, sizeof(float) * 16);
-        res[k][j].converged = 0; res[k][j].iterations = 0; res[k][j].evaluations = 0; res[k][j].status = rcs[k];
-        res[k][j].score = 0.0; res[k][j].fitness = NAN;
-      }
-    }
-  // ---- the exchange step: fixed-size records, all-gathered over RCCL (xGMI) when the group has communicators
-  std::vector<Record> all((size_t)G * per);
-  for (auto& r : all) { std::memset(&r, 0, sizeof(r)); r.candidate = -1; }
-  auto fill = [&](int k, Record* dst) {
-    for (size_t j = 0; j < res[k].size(); j++) {
-      Record& r = dst[j];
-      const dgs_result& a = res[k][j];
-      r.fitness = a.fitness; r.score = a.score;
-      std::memcpy(r.T, a.final_transformation, sizeof(r.T));
-      r.candidate = (int32_t)(k + (int)j * G);
-      r.converged = a.converged; r.iterations = a.iterations; r.evaluations = a.evaluations; r.status = a.status;
-    }
+  auto run = [&](int k, const float* gk, dgs_result* out) {
+    return dgs_align_batch(g->members[k], (int32_t)src[k].size(), src[k].data(), sz[k].data(), 0, gk, compute_fitness, fitness_max_range, out);
   };
-  bool gathered = false;
-  if (!g->comms.empty() && ensure_buffers(g, (size_t)per)) {
-    bool ok = true;
-    for (int k = 0; k < G && ok; k++) {
-      char* hs = static_cast<char*>(g->h_stage[k]);
-      std::memset(hs, 0, (size_t)per * kRecordBytes);
-      std::vector<Record> mine(per);
-      for (auto& r : mine) { std::memset(&r, 0, sizeof(r)); r.candidate = -1; }
-      fill(k, mine.data());
-      for (int j = 0; j < per; j++) std::memcpy(hs + (size_t)j * kRecordBytes, &mine[j], sizeof(Record));
-      ok = hipSetDevice(g->devices[k]) == hipSuccess &&
-           hipMemcpyAsync(g->d_send[k], hs, (size_t)per * kRecordBytes, hipMemcpyHostToDevice, g->members[k]->stream) == hipSuccess;
-    }
-    if (ok) {
-      ok = g->rccl.GroupStart() == 0;
-      for (int k = 0; k < G && ok; k++)
-        ok = g->rccl.AllGather(g->d_send[k], g->d_recv[k], (size_t)per * kRecordBytes, kNcclUint8, g->comms[k], g->members[k]->stream) == 0;
-      ok = (g->rccl.GroupEnd() == 0) && ok;
-    }
-    // member 0 holds everybody's records after the collective: one device->host copy
-    if (ok) {
-      char* hs = static_cast<char*>(g->h_stage[0]);
-      ok = hipSetDevice(g->devices[0]) == hipSuccess &&
-           hipMemcpyAsync(hs, g->d_recv[0], (size_t)G * per * kRecordBytes, hipMemcpyDeviceToHost, g->members[0]->stream) == hipSuccess;
-      for (int k = 0; k < G && ok; k++) ok = hipSetDevice(g->devices[k]) == hipSuccess && hipStreamSynchronize(g->members[k]->stream) == hipSuccess;
-      if (ok) {
-        for (size_t j = 0; j < (size_t)G * per; j++) std::memcpy(&all[j], hs + j * kRecordBytes, sizeof(Record));
-        gathered = true;
-        g->used_rccl = true;
-      }
-    }
-    if (!ok) g->err = "dgs_group: RCCL all-gather failed, gathered on the host instead";
+  return run_dealt_batch(g, n, ids, guesses16, compute_fitness, run, results, best_index, best_score);
+}
+
+// ---- keyframe clouds resident on the group's devices -----------------------------------------------------------------------------
+int dgs_group_cloud_create(dgs_group* g, const float* xyz16, int64_t n, int32_t owner, dgs_group_cloud** out) {
+  if (!g || !out || n < 0 || (n > 0 && !xyz16) || owner < -1) return DGS_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  g->err.clear();
+  DeviceScope keep;
+  const int G = (int)g->members.size();
+  dgs_group_cloud* c = new (std::nothrow) dgs_group_cloud();
+  if (!c) return DGS_ERR_HIP;
+  c->copy.assign(G, nullptr);
+  c->n = n;
+  const int only = owner < 0 ? -1 : owner % G;
+  const int rc = for_each_member(g, [g, c, xyz16, n](int k) { return dgs_cloud_create(g->members[k], xyz16, n, 0, &c->copy[k]); },
+                                 [only](int k) { return only < 0 || k == only; });
+  if (rc != DGS_OK) {
+    dgs_group_cloud_destroy(c);
+    return rc;
   }
-  if (!gathered)
-    for (int k = 0; k < G; k++) fill(k, all.data() + (size_t)k * per);
-  // ---- results back in ORIGINAL candidate order, then the arg-min of loop_detector.hpp:126-156
-  for (const Record& r : all) {
-    if (r.candidate < 0 || r.candidate >= n) continue;
-    dgs_result& o = results[r.candidate];
-    std::memcpy(o.final_transformation, r.T, sizeof(r.T));
-    o.converged = r.converged; o.iterations = r.iterations; o.evaluations = r.evaluations; o.status = r.status;
-    o.score = r.score; o.fitness = r.fitness;
-  }
-  double best = DBL_MAX;
-  int bi = -1;
-  if (compute_fitness)
-    for (int c = 0; c < n; c++) {
-      if (!results[c].converged || results[c].fitness > best || results[c].fitness != results[c].fitness) continue;   // "score > best_score" skips; ties: the later wins
-      best = results[c].fitness;
-      bi = c;
-    }
-  if (best_index) *best_index = bi;
-  if (best_score) *best_score = best;
+  *out = c;
   return DGS_OK;
+}
+
+void dgs_group_cloud_destroy(dgs_group_cloud* c) {
+  if (!c) return;
+  DeviceScope keep;
+  for (dgs_cloud* m : c->copy)
+    if (m) dgs_cloud_destroy(m);
+  delete c;
+}
+
+int64_t dgs_group_cloud_size(const dgs_group_cloud* c) { return c ? c->n : 0; }
+
+int32_t dgs_group_cloud_copies(const dgs_group_cloud* c) {
+  int32_t m = 0;
+  if (c)
+    for (dgs_cloud* x : c->copy) m += x ? 1 : 0;
+  return m;
+}
+
+int dgs_group_set_input_target_cloud(dgs_group* g, dgs_group_cloud* c) {
+  if (!g || !c || c->copy.size() != g->members.size()) return DGS_ERR_INVALID_ARGUMENT;
+  g->err.clear();
+  DeviceScope keep;
+  int holder = -1;
+  for (size_t k = 0; k < c->copy.size() && holder < 0; k++)
+    if (c->copy[k]) holder = (int)k;
+  if (holder < 0) return DGS_ERR_INVALID_ARGUMENT;
+  // the new keyframe is every member's target: members without a copy take one from a holder, device to device (xGMI), and keep it
+  return for_each_member(g, [g, c, holder](int k) {
+    if (!c->copy[k]) {
+      const int rc = dgs::cloud_clone_to(g->members[k], c->copy[holder], &c->copy[k]);
+      if (rc != DGS_OK) return rc;
+    }
+    return dgs_set_input_target_cloud(g->members[k], c->copy[k]);
+  });
+}
+
+int dgs_group_align_batch_clouds(dgs_group* g, int32_t n, dgs_group_cloud* const* sources, const float* guesses16, int32_t compute_fitness,
+                                 double fitness_max_range, dgs_result* results, int32_t* best_index, double* best_score) {
+  if (!g || n < 0 || (n > 0 && (!sources || !results))) return DGS_ERR_INVALID_ARGUMENT;
+  g->err.clear();
+  g->used_rccl = false;
+  if (best_index) *best_index = -1;
+  if (best_score) *best_score = DBL_MAX;
+  if (n == 0) return DGS_OK;
+  DeviceScope keep;
+  const int G = (int)g->members.size();
+  // ---- deal: candidate c -> member c mod G when that member holds the keyframe, else the keyframe's first holder (its owner)
+  std::vector<std::vector<int>> ids(G);
+  std::vector<std::vector<dgs_cloud*>> cl(G);
+  for (int c = 0; c < n; c++) {
+    const dgs_group_cloud* s = sources[c];
+    if (!s || (int)s->copy.size() != G) return DGS_ERR_INVALID_ARGUMENT;
+    int k = c % G;
+    if (!s->copy[k]) {
+      k = -1;
+      for (int j = 0; j < G && k < 0; j++)
+        if (s->copy[j]) k = j;
+      if (k < 0) return DGS_ERR_INVALID_ARGUMENT;
+    }
+    ids[k].push_back(c);
+    cl[k].push_back(s->copy[k]);
+  }
+  auto run = [&](int k, const float* gk, dgs_result* out) {
+    return dgs_align_batch_clouds(g->members[k], (int32_t)cl[k].size(), cl[k].data(), gk, compute_fitness, fitness_max_range, out);
+  };
+  return run_dealt_batch(g, n, ids, guesses16, compute_fitness, run, results, best_index, best_score);
 }
 
 int32_t dgs_group_last_gather_used_rccl(const dgs_group* g) { return (g && g->used_rccl) ? 1 : 0; }

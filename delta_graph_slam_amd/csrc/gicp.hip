@@ -501,8 +501,8 @@ __device__ __forceinline__ void gicp_block_reduce(const double* acc, double* __r
     double v = 0.0;
     if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
     if (FUSED) {
-      __hip_atomic_store(row + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: see gicp_close_round
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      handoff_store_row(row + threadIdx.x, v);   // write-through: see gicp_close_round and common.h, "in-launch hand-off"
+      handoff_drain_stores();
     } else {
       row[threadIdx.x] = v;
     }
@@ -664,7 +664,7 @@ __device__ __forceinline__ void gicp_step_from_rows(GicpPair* st, const double* 
   double v = 0.0;
   for (int b = grp; b < nblocks; b += G) {
     const double* r = partials + (size_t)b * kAccumPad + col;
-    v += FUSED ? __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *r;
+    v += FUSED ? handoff_load_row(r) : *r;
   }
   sm[grp][col] = v;
   {  // state -> LDS, word by word, by the whole workgroup
@@ -728,10 +728,7 @@ __device__ __forceinline__ void gicp_close_round(GicpPair* pairs, const int pair
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(&pairs[pair].ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == nblocks - 1) ? 1 : 0;
-    if (last) pairs[pair].ticket = 0;
-    s_last = last;
+    s_last = handoff_take_ticket(&pairs[pair].ticket, nblocks) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;

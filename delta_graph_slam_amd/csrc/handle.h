@@ -177,6 +177,7 @@ struct dgs_handle {
   bool have_result = false;
 
   dgs::DevBuf<double> nn_partials;
+  const double* nn_out = nullptr;   // device: {sum, count, inliers, 0} per pair of the last fitness batch (inside nn_partials; read by dgs_group's record kernel)
   dgs::DevBuf<float4> scratch_cloud;
   dgs::NnGrid tgt_grid, aux_grid;   // fitness-pass index over the current target / over cloud1 of dgs_calc_fitness_score
   int grid_mode = 0;                // DGS_NN_GRID at dgs_create: 0 (default) tree walk only, >= 1 grid pass in front of it, -1 grid pass for big batches.
@@ -245,11 +246,21 @@ int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, f
 int ensure_target_index(dgs_handle* h, hipStream_t st = nullptr);   // tree (+ grid when h->use_grid) over the current target
 // the grid pass pays for its build (one more sort of the target) from ~4 x 65,536 queries on: fitness of a candidate batch
 inline bool grid_wanted(const dgs_handle* h, int64_t queries) { return h->grid_mode > 0 || (h->grid_mode < 0 && queries >= 262144); }
-// nn_grid.hip
+// nn_grid.hip -- the one-lane-per-query voxel-hierarchy fitness index: measured slower than the 8-lane tree walk, so it
+// is part of the EXPERIMENTS build only (`make experiments` -> libdgs_reg_exp.so, -DDGS_EXPERIMENTS); the product library does not
+// carry its kernels and ignores DGS_NN_GRID.
+#ifdef DGS_EXPERIMENTS
+constexpr bool kExperiments = true;
 int nn_grid_build(dgs_handle* h, NnGrid& G, const Bvh& bvh, const float4* pts, int64_t n, hipStream_t st = nullptr);
 int nn_grid_launch_fitness(dgs_handle* h, NnGrid& G, const Bvh& index, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_n, const float* d_T,
                            size_t T_stride_bytes, float max_range, float inlier_sq, double* partial, int bpp);
 int nn_grid_search(dgs_handle* h, NnGrid& G, const Bvh& index, const float4* queries, int64_t m, float* d_sq);
+#else
+constexpr bool kExperiments = false;
+inline int nn_grid_build(dgs_handle*, NnGrid&, const Bvh&, const float4*, int64_t, hipStream_t = nullptr) { return DGS_ERR_UNSUPPORTED; }
+inline int nn_grid_launch_fitness(dgs_handle*, NnGrid&, const Bvh&, int, const float4* const*, const int*, int, const float*, size_t, float, float, double*, int) { return DGS_ERR_UNSUPPORTED; }
+inline int nn_grid_search(dgs_handle*, NnGrid&, const Bvh&, const float4*, int64_t, float*) { return DGS_ERR_UNSUPPORTED; }
+#endif
 // gicp.hip
 int vgicp_build_map(dgs_handle* h);  // vgicp_voxel.hip: needs the target covariances
 int vgicp_voxels(dgs_handle* h, int64_t capacity, int32_t* coord3, int32_t* counts, double* mean3, double* cov9, int64_t* n_voxels);
@@ -261,5 +272,7 @@ int gicp_covariances(dgs_handle* h, int which, double* host_out6, int64_t n);
 int gicp_probe(dgs_handle* h, const double* T16_rowmajor, int error_only, double* err, double* H36, double* b6);
 // transform
 int transform_cloud(dgs_handle* h, const float4* in, float4* out, int64_t n, const float* T16_colmajor_host);
+// dgs_api.hip: a copy of `src` (points only) on dst_h's device, device to device (peer copy over xGMI when the devices differ)
+int cloud_clone_to(dgs_handle* dst_h, const dgs_cloud* src, dgs_cloud** out);
 
 }  // namespace dgs

@@ -83,7 +83,7 @@ __device__ __forceinline__ v2f affine_row_rn2(float m0, float m1, float m2, floa
   return ((m0 * x + m1 * y) + m2 * z) + m3;   // v_pk_mul_f32 / v_pk_add_f32: every element individually rounded, as affine_row_rn
 }
 
-// PACK2: two source points per lane and step, the float fold and projection written on 2-vectors so that they compile to
+// PACK2 (instantiated in the EXPERIMENTS build only: measured 29-46 % slower): two source points per lane and step, the float fold and projection written on 2-vectors so that they compile to
 // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two points per instruction); look-ups, the double q = x' - mean, exp and the
 // double accumulation stay per point.  The per-thread order of accumulation is unchanged (i, i + stride, i + 2 stride, ...).
 template <int SEARCH, bool FUSED, bool PACK2>
@@ -397,20 +397,15 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
     double v = 0.0;
     if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
     double* row = partials + ((size_t)pair * cap_blocks + slice) * kAccumPad + threadIdx.x;
-    if (FUSED) __hip_atomic_store(row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1): no release fence needed
+    if (FUSED) handoff_store_row(row, v);   // write-through (sc1): no release fence needed (common.h, "in-launch hand-off")
     else *row = v;
   }
   if (!FUSED) return;
   // ---- publish this slice's row, take a ticket; the workgroup that takes the pair's last ticket closes the evaluation
   __shared__ int s_last;
-  if (threadIdx.x < kAccumPad) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains its stores
+  if (threadIdx.x < kAccumPad) handoff_drain_stores();   // the storing wave drains its stores
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(&pairs[pair].ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == blocks_per_pair - 1) ? 1 : 0;
-    if (last) pairs[pair].ticket = 0;   // for the next launch (ordered by the kernel boundary)
-    s_last = last;
-  }
+  if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, blocks_per_pair) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
 #ifdef DGS_CLOSE_STAMPS
@@ -1006,7 +1001,7 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
       const int b = b0 + k * G;
       const double* ptr = partials_of_pair + (size_t)min(b, blocks_per_pair - 1) * kAccumPad + col;
       // rows published inside this launch: agent-scope (sc1) loads, never a line this CU may hold from an earlier launch
-      const double x = (launch >= 0) ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+      const double x = (launch >= 0) ? handoff_load_row(ptr) : *ptr;
       r[k] = (b < blocks_per_pair) ? x : 0.0;
     }
     v = (((v + r[0]) + r[1]) + r[2]) + r[3];
@@ -1265,8 +1260,10 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
       case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, true, false); break;
       case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, true, false); break;
       default:
-        if (h->ndt_pack2) DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true, true);
-        else DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true, false);
+#ifdef DGS_EXPERIMENTS
+        if (h->ndt_pack2) { DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true, true); break; }
+#endif
+        DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, true, false);
         break;
     }
   } else {
@@ -1275,8 +1272,10 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
       case DGS_NDT_DIRECT26: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT26, false, false); break;
       case DGS_NDT_KDTREE: DGS_LAUNCH_DERIV(DGS_NDT_KDTREE, false, false); break;
       default:
-        if (h->ndt_pack2) DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false, true);
-        else DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false, false);
+#ifdef DGS_EXPERIMENTS
+        if (h->ndt_pack2) { DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false, true); break; }
+#endif
+        DGS_LAUNCH_DERIV(DGS_NDT_DIRECT7, false, false);
         break;
     }
   }

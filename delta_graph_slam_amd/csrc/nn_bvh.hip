@@ -554,6 +554,7 @@ int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pai
   const int bpp = std::max(1, std::min(full, std::max(64, total_blocks / std::max(1, n_pairs))));
   DGS_HIP_TRY(h, h->nn_partials.reserve((size_t)n_pairs * bpp * 4 + (size_t)n_pairs * 4));
   double* d_out = h->nn_partials.ptr + (size_t)n_pairs * bpp * 4;
+  h->nn_out = d_out;
   if (ensure_pinned(h, 4096 + sizeof(double) * 4 * n_pairs) != DGS_OK) return DGS_ERR_HIP;
   // PCL's comparison is float(sq_dist) <= double(max_range); clamp so DBL_MAX keeps every finite distance
   const float mr = (max_range >= (double)FLT_MAX) ? FLT_MAX : (float)max_range;

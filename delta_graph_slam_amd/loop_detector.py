@@ -77,13 +77,16 @@ class LoopDetector:
         self.cache_clouds = bool(cache_clouds)
         self._cloud_cache = {}
 
-    def resident(self, keyframe: "KeyFrame"):
+    def resident(self, keyframe: "KeyFrame", as_target: bool = False):
         """KeyFrame::cloud as the registration should see it: the cached HBM-resident object when caching is on."""
         if not self.cache_clouds or keyframe.id < 0 or not hasattr(self.registration, "make_cloud"):
             return keyframe.cloud
         c = self._cloud_cache.get(keyframe.id)
         if c is None:
-            c = self.registration.make_cloud(keyframe.cloud)
+            if as_target or not hasattr(self.registration, "devices"):
+                c = self.registration.make_cloud(keyframe.cloud)
+            else:   # a group (several devices, one process): a candidate keyframe lives on ONE member, owner = its id (even shares)
+                c = self.registration.make_cloud(keyframe.cloud, owner=keyframe.id)
             self._cloud_cache[keyframe.id] = c
         return c
 
@@ -142,7 +145,7 @@ class LoopDetector:
         gathered [n_candidates, RECORD_WIDTH] float64 records in original candidate order."""
         rank, world = self._world()
         n = len(candidates)
-        self.registration.setInputTarget(self.resident(new_keyframe))
+        self.registration.setInputTarget(self.resident(new_keyframe, as_target=True))
         mine = list(range(rank, n, world))
         sources = [self.resident(candidates[c]) for c in mine]
         guesses = self.guesses_for(new_keyframe, [candidates[c] for c in mine])

@@ -24,7 +24,7 @@ try:  # torch is plumbing only: device memory + streams
 except Exception:  # pragma: no cover
     torch = None
 
-__all__ = ["Registration", "RegistrationGroup", "DeviceCloud", "select_registration_method", "DgsError"]
+__all__ = ["Registration", "RegistrationGroup", "DeviceCloud", "GroupCloud", "select_registration_method", "DgsError"]
 DgsError = L.DgsError
 
 
@@ -95,9 +95,14 @@ class DeviceCloud:
 class Registration:
     """pcl::Registration-shaped object backed by one dgs_handle (HIP, gfx950)."""
 
-    def __init__(self, method: str = "NDT_OMP", device: int | None = None, **params):
-        lib = L.load()
+    def __init__(self, method: str = "NDT_OMP", device: int | None = None, _borrow=None, lib_path: str | None = None, **params):
+        lib = L.load(lib_path)   # lib_path: another build of the library (tests of the experiments build)
         self._lib = lib
+        self._owns = _borrow is None
+        if _borrow is not None:   # a dgs_group member's handle (RegistrationGroup.member): the group owns and destroys it
+            self.method, self.params, self._h = method, None, C.c_void_p(_borrow)
+            self._converged, self._final, self.last_result, self._keep = False, np.eye(4, dtype=np.float32), None, {}
+            return
         exact = {"NDT_OMP": L.METHOD_NDT, "NDT_HIP": L.METHOD_NDT, "FAST_GICP": L.METHOD_GICP, "FAST_GICP_HIP": L.METHOD_GICP,
                  "FAST_VGICP": L.METHOD_VGICP, "FAST_VGICP_HIP": L.METHOD_VGICP}
         if method not in exact:   # pcl::ICP / GICP / NDT, pclomp::GICP, FAST_VGICP_CUDA are other algorithms: not served here
@@ -127,7 +132,8 @@ class Registration:
     # -- lifetime ---------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
-            self._lib.dgs_destroy(self._h)
+            if getattr(self, "_owns", True):
+                self._lib.dgs_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -399,6 +405,38 @@ class Registration:
         return dict(keys=keys[keep][o], counts=counts[keep][o], valid=valid[keep][o].astype(bool), mean=mean[keep][o], icov=icov[keep][o])
 
 
+class GroupCloud:
+    """dgs_group_cloud: KeyFrame::cloud (keyframe.hpp:51) resident on a group's devices -- on one member (`owner` >= 0: member
+    owner mod G) or on every member (`owner` None / -1: the new keyframe, every member's target)."""
+
+    def __init__(self, group: "RegistrationGroup", cloud, owner=None):
+        ptr, n, dev, keep = _cloud_ptr(cloud)
+        if dev:
+            raise ValueError("a group cloud is uploaded from the host (KeyFrame::cloud)")
+        self._lib = group._lib
+        self._c = C.c_void_p()
+        group._check(self._lib.dgs_group_cloud_create(group._g, ptr, n, -1 if owner is None or owner < 0 else int(owner), C.byref(self._c)))
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def copies(self) -> int:
+        return int(self._lib.dgs_group_cloud_copies(self._c))
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self._lib.dgs_group_cloud_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class RegistrationGroup:
     """dgs_group (include/dgs_reg.h): the candidate loop of LoopDetector::matching (loop_detector.hpp:137-156) sharded over
     several GPUs of ONE process -- candidate c goes to device c mod G, the result records come back through an RCCL all-gather
@@ -421,6 +459,7 @@ class RegistrationGroup:
                 raise TypeError(f"unknown registration parameter {k!r}")
             setattr(p, k, v)
         self.devices = [int(d) for d in devices]
+        self.method = method
         dv = (C.c_int32 * len(self.devices))(*self.devices)
         self._g = C.c_void_p()
         rc = lib.dgs_group_create(C.byref(p), dv, len(self.devices), C.byref(self._g))
@@ -452,10 +491,24 @@ class RegistrationGroup:
     def last_gather_used_rccl(self) -> bool:
         return bool(self._lib.dgs_group_last_gather_used_rccl(self._g))
 
+    def member(self, k: int) -> "Registration":
+        """Member k's handle as a (borrowed) Registration: measurement hooks (profile_*, counts) of one device of the group."""
+        h = self._lib.dgs_group_member(self._g, int(k))
+        if not h:
+            raise IndexError(k)
+        return Registration(self.method, _borrow=h)
+
+    def make_cloud(self, cloud, owner=None) -> GroupCloud:
+        return GroupCloud(self, cloud, owner)
+
     def setInputTarget(self, cloud):
+        if isinstance(cloud, GroupCloud):
+            self._keep_target = cloud
+            self._check(self._lib.dgs_group_set_input_target_cloud(self._g, cloud._c))
+            return
         ptr, n, dev, keep = _cloud_ptr(cloud)
         if dev:
-            raise ValueError("a group takes host clouds (KeyFrame::cloud); each member uploads its own copy")
+            raise ValueError("a group takes host clouds (KeyFrame::cloud) or GroupCloud objects; each member holds its own copy")
         self._check(self._lib.dgs_group_set_input_target(self._g, ptr, n))
 
     def _raw(self, sources, guesses, compute_fitness, fitness_max_range):
@@ -465,6 +518,14 @@ class RegistrationGroup:
             ga = np.asarray(guesses, dtype=np.float32)
             g = np.ascontiguousarray(ga.transpose(0, 2, 1).reshape(n, 16)) if ga.ndim == 3 else np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
             gp = g.ctypes.data_as(C.c_void_p)
+        if n and all(isinstance(s_, GroupCloud) for s_ in sources):   # resident keyframes: nothing is uploaded
+            cl = (C.c_void_p * n)(*[s_._c.value for s_ in sources])
+            res = (L.Result * n)()
+            bi = C.c_int32(-1)
+            bs = C.c_double(0)
+            self._check(self._lib.dgs_group_align_batch_clouds(self._g, n, cl, gp, 1 if compute_fitness else 0, fitness_max_range, res, C.byref(bi), C.byref(bs)))
+            self.best_index, self.best_score = bi.value, bs.value
+            return res
         ptrs = (C.c_void_p * n)()
         sizes = (C.c_int64 * n)()
         keep = []
@@ -509,11 +570,13 @@ def select_registration_method(params: dict | None = None, device: int | None = 
     `params` plays the role of the private NodeHandle: keys are the reference's rosparam names
     (registration_method, reg_num_threads, reg_transformation_epsilon, reg_maximum_iterations,
     reg_max_correspondence_distance, reg_correspondence_randomness, reg_resolution, reg_nn_search_method).
-    "NDT_HIP" / "NDT_OMP" select NDT (pclomp, registrations.cpp:101-120); "FAST_GICP_HIP" / "FAST_GICP" select GICP (:27-36);
-    "FAST_VGICP_HIP" / "FAST_VGICP" the voxelised GICP (:48-56).  The reference's other branches -- "ICP" (:59-64), "GICP" (:68-75),
-    "GICP_OMP" (:78-85), plain "NDT" (pcl::NDT, :96-100), "FAST_VGICP_CUDA" (:37-47) -- are different algorithms that stay with the
-    unpatched factory: here they raise NotImplementedError instead of silently running something else.  Names the reference
-    does not know either warn and fall to NDT_OMP exactly like registrations.cpp:88-91,121-123.
+    "NDT_HIP" selects the HIP NDT; "FAST_GICP_HIP" / "FAST_GICP" select GICP (:27-36); "FAST_VGICP_HIP" / "FAST_VGICP" the voxelised
+    GICP (:48-56).  Every other name goes through the reference's own chain of tests, in its order: "ICP" (:59-64) and any name
+    containing "GICP" (:66-87: pcl::GICP, or pclomp::GICP when it also contains "OMP") are different algorithms -> NotImplementedError;
+    what is left is the NDT branch (:88-123): a name without "NDT" warns "unknown registration type ... use NDT" (:89-92), and then
+    a name without "OMP" -- plain "NDT" as well as an unknown name such as "FOO" -- is pcl::NormalDistributionsTransform (:94-100),
+    another algorithm -> NotImplementedError, while a name containing "OMP" ("NDT_OMP", and e.g. "FOO_OMP" after the warning) is
+    pclomp::NormalDistributionsTransform (:101-120), which this library serves.
     """
     pr = dict(params or {})
     method = pr.get("registration_method", "NDT_OMP")
@@ -527,11 +590,15 @@ def select_registration_method(params: dict | None = None, device: int | None = 
     if method in ("FAST_VGICP", "FAST_VGICP_HIP"):      # registrations.cpp:48-56
         return Registration("FAST_VGICP", device=device, vgicp_resolution=float(pr.get("reg_resolution", 1.0)),
                             gicp_correspondence_randomness=int(pr.get("reg_correspondence_randomness", 20)), **common)
-    if method in ("ICP", "GICP", "GICP_OMP", "NDT", "FAST_VGICP_CUDA"):
+    if method == "ICP" or "GICP" in method:             # :59-64, :66-87 (FAST_VGICP_CUDA lands here too when the reference is built without CUDA)
         raise NotImplementedError(f"registration_method {method!r} is served by the reference's own factory branch, not by the HIP back-ends")
-    if method not in ("NDT_OMP", "NDT_HIP"):
-        import sys
-        print(f"warning: unknown registration type({method})\n       : use NDT", file=sys.stderr)
+    if method != "NDT_HIP":
+        if "NDT" not in method:                         # :89-92
+            import sys
+            print(f"warning: unknown registration type({method})\n       : use NDT", file=sys.stderr)
+        if "OMP" not in method:                         # :94-100 pcl::NormalDistributionsTransform
+            raise NotImplementedError(f"registration_method {method!r} selects pcl::NormalDistributionsTransform in the reference "
+                                      "(registrations.cpp:94-100), a different algorithm from NDT_OMP: not served by the HIP back-ends")
     nn = pr.get("reg_nn_search_method", "DIRECT7")
     search = L.NDT_SEARCH["KDTREE"] if nn == "KDTREE" else L.NDT_SEARCH["DIRECT1"] if nn == "DIRECT1" else L.NDT_SEARCH["DIRECT7"]
     return Registration("NDT_OMP", device=device, ndt_resolution=float(pr.get("reg_resolution", 0.5)), ndt_search_method=search, **common)

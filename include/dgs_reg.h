@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 3
+#define DGS_ABI_VERSION 4
 
 typedef struct dgs_handle dgs_handle;
 typedef struct dgs_cloud dgs_cloud; /* a cloud resident in HBM together with its NN index / covariances (see below) */
@@ -234,7 +234,10 @@ int dgs_approx_voxel_grid_filter(dgs_handle* h, const float* in_xyz16, int64_t n
  * loop_detector.hpp:126-156 over (converged, fitness) with its tie rule (on an equal score the later candidate wins), -1 /
  * DBL_MAX when no candidate converged.  The fitness_score_thresh test (:162) stays with the caller.  A group whose device list
  * names one device twice (a one-GPU rehearsal), or that cannot load RCCL, gathers on the host instead: same results.
- * Sources and the target are host arrays (KeyFrame::cloud); a group is used by one thread at a time. */
+ * Every member writes the records of its share ON THE DEVICE (optimiser state + fitness sums -> record), so the all-gather sends what
+ * the kernels left in HBM; the group's functions leave the caller's current HIP device unchanged.
+ * Sources and the target are host arrays (KeyFrame::cloud) or, below, clouds resident on the group's devices; a group is used by
+ * one thread at a time. */
 typedef struct dgs_group dgs_group;
 int dgs_group_create(const dgs_params* params, const int32_t* devices, int32_t n_devices, dgs_group** out); /* params->device is ignored */
 void dgs_group_destroy(dgs_group* g);
@@ -246,6 +249,25 @@ dgs_handle* dgs_group_member(dgs_group* g, int32_t k);         /* member k's han
 int dgs_group_set_input_target(dgs_group* g, const float* xyz16, int64_t n);
 int dgs_group_align_batch(dgs_group* g, int32_t n, const float* const* sources, const int64_t* sizes, const float* guesses16,
                           int32_t compute_fitness, double fitness_max_range, dgs_result* results, int32_t* best_index, double* best_score);
+
+/* Keyframe clouds resident on the group's devices.  KeyFrame::cloud is set once and never written again
+ * (/root/reference/include/hdl_graph_slam/keyframe.hpp:51) and the same keyframes are candidates tick after tick
+ * (apps/delta_graph_slam_nodelet.cpp:816 -> loop_detector.hpp:59-70), so a nodelet uploads each keyframe ONCE:
+ *   owner >= 0: one copy, on member owner mod G (a candidate keyframe: owner = its id keeps the shares even);
+ *   owner = -1: a copy on every member (the new keyframe, which is every member's target).
+ * dgs_group_set_input_target_cloud = loop_detector.hpp:124 on every member; members without a copy take one from a holder, device
+ * to device over xGMI, and keep it (a keyframe is a target first and a candidate on later ticks).
+ * dgs_group_align_batch_clouds = dgs_group_align_batch without any upload: candidate c runs on member c mod G when that member
+ * holds its cloud, else on the cloud's owner; results, arg-min and tie rule as above.  A dgs_group_cloud belongs to the group it
+ * was created with (may be destroyed before or after it). */
+typedef struct dgs_group_cloud dgs_group_cloud;
+int dgs_group_cloud_create(dgs_group* g, const float* xyz16, int64_t n, int32_t owner, dgs_group_cloud** out);
+void dgs_group_cloud_destroy(dgs_group_cloud* cloud);
+int64_t dgs_group_cloud_size(const dgs_group_cloud* cloud);
+int32_t dgs_group_cloud_copies(const dgs_group_cloud* cloud);   /* members that hold a copy */
+int dgs_group_set_input_target_cloud(dgs_group* g, dgs_group_cloud* cloud);
+int dgs_group_align_batch_clouds(dgs_group* g, int32_t n, dgs_group_cloud* const* sources, const float* guesses16, int32_t compute_fitness,
+                                 double fitness_max_range, dgs_result* results, int32_t* best_index, double* best_score);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) ---------------------- */
 enum dgs_kernel_id {

@@ -378,3 +378,41 @@ def approx_voxel_grid(cloud, leaf: float) -> np.ndarray:
     L.orc_approx_voxel_grid.restype = C.c_int64
     m = L.orc_approx_voxel_grid(pc, C.c_int64(c.shape[0]), C.c_float(leaf), out.ctypes.data_as(C.POINTER(C.c_float)))
     return out[:m].copy()
+
+
+def pose_error(Ta, Tb):
+    """(translation error [m], rotation angle error [rad]) between two 4x4 transforms."""
+    Ta = np.asarray(Ta, np.float64)
+    Tb = np.asarray(Tb, np.float64)
+    dt = np.linalg.norm(Ta[:3, 3] - Tb[:3, 3])
+    R = Ta[:3, :3].T @ Tb[:3, :3]
+    w = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])   # skew part: accurate for tiny angles
+    return float(dt), float(np.arctan2(np.linalg.norm(w), 0.5 * (np.trace(R) - 1.0)))
+
+
+def _ulp_shift(G, k):
+    """Move the guess translation by k float32 ulps (x up, y down): a perturbation below the input's own resolution."""
+    Gp = np.asarray(G, np.float32).copy()
+    for _ in range(abs(k)):
+        Gp[0, 3] = np.nextafter(Gp[0, 3], np.float32(np.inf if k > 0 else -np.inf))
+        Gp[1, 3] = np.nextafter(Gp[1, 3], np.float32(-np.inf if k > 0 else np.inf))
+    return Gp
+
+
+def ndt_band(tgt, src, guess=None, twins=None, **kw):
+    """The restated algorithm's own reproducibility on one pair: the largest deviation of its answer under perturbations that
+    carry no information -- the same source compiled with FMA contraction, the host libm's expf instead of the platform-independent
+    one, and the float32 initial guess moved by +-1 and +-2 ulps.  `twins` selects a subset (tuples (perturbed build, exp_libm,
+    ulps)).  Returns (result of the unperturbed run, band_translation [m], band_rotation [rad])."""
+    G = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, np.float32)
+    if twins is None:
+        twins = ((True, 0, 0), (False, 1, 0), (False, 0, 1), (False, 0, -1), (False, 0, 2), (False, 0, -2))
+    runs = []
+    for perturbed, libm, k in ((False, 0, 0),) + tuple(twins):
+        o = NdtOracle(perturbed=perturbed, exp_libm=libm, **kw)
+        o.set_target(tgt)
+        o.set_source(src)
+        runs.append(o.align(_ulp_shift(G, k)))
+    bt = max(pose_error(r["T"], runs[0]["T"])[0] for r in runs[1:])
+    br = max(pose_error(r["T"], runs[0]["T"])[1] for r in runs[1:])
+    return runs[0], bt, br

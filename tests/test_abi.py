@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in dgs_reg.h but not exported"
     assert sorted(L.SYMBOLS) == declared
-    assert lib.dgs_abi_version() == 3
+    assert lib.dgs_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header():
@@ -121,3 +121,16 @@ def test_group_has_no_cpu_fallback_either():
     dv = (C.c_int32 * 2)(0, 1)
     assert lib.dgs_group_create(C.byref(p), dv, 2, C.byref(g)) == 2 and not g.value
     assert lib.dgs_group_size(None) == 0 and lib.dgs_group_uses_rccl(None) == 0
+
+
+def test_product_library_carries_only_the_measured_winners():
+    """the voxel-hierarchy fitness index (nn_grid.hip) and the packed-FP32 derivative kernel are measured losers; they
+    live in the experiments build (`make experiments`), not in the library a nodelet links."""
+    from delta_graph_slam_amd import _lib as L
+    prod = open(L.LIB_PATH, "rb").read()
+    pack2 = b"ndt_derivatives_kernelILi2ELb1ELb1EE"     # <DIRECT7, fused, PACK2>
+    assert b"nn_grid" not in prod and pack2 not in prod
+    if os.path.exists(L.EXPERIMENTS_LIB_PATH):
+        exp = open(L.EXPERIMENTS_LIB_PATH, "rb").read()
+        assert b"nn_grid" in exp and pack2 in exp
+        assert len(prod) < len(exp)

@@ -50,3 +50,37 @@ def test_traffic_leg_refuses_to_nest_profilers(monkeypatch):
         if k.startswith(bench.PROFILER_ENV_PREFIXES):
             monkeypatch.delenv(k)
     assert not bench.under_profiler()
+
+
+def test_group_mode_stays_in_one_process_and_reports_the_group_shape():
+    """`bench.py --gpus N --group`: ONE process, N devices behind dgs_group -- nothing is spawned, the dealing is c -> c mod N."""
+    out = _run(["--gpus", "4", "--group", "--dry-run", "--steps", "3", "--warmup", "1", "--pairs", "5"])
+    cfg = out["config"]
+    assert out["n_gpus"] == 4 and out["dry_run"] is True and out["value"] is None and out["scaling"] == "weak"
+    assert cfg["group"] is True and cfg["processes"] == 1 and cfg["members"] == 4 and cfg["candidates_per_step"] == 20 and cfg["shares"] == [5, 5, 5, 5]
+    assert cfg["collective_backend"].startswith("rccl")
+
+
+def test_cpu_baseline_child_times_the_oracle_with_pinned_threads(tmp_path):
+    """The cpu_baseline leg runs in a child process (OMP_PROC_BIND / OMP_PLACES must not reach the process that drives the GPU):
+    thread sweep, three repeats, per-pair and per-evaluation times, the fitness loop on the same pairs, the poses for the parity gate."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    from delta_graph_slam_amd import synth
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=3, n_points=4096, seed=5, distinct_scans=2)
+    args = bench.parse_args(["--cpu-seconds", "2", "--pairs", "3"])
+    res = bench.run_cpu_baseline(args, tgt, sources, guesses)
+    assert "error" not in res, res
+    cb = res["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "registrations/s" and cb["value"] > 0 and cb["cores"] >= 1
+    lo, hi = cb["value_spread_3_repeats"]
+    assert lo <= cb["value"] <= hi and cb["value_with_fitness_score"] < cb["value"]      # the fitness loop only adds work, on the same pairs
+    assert cb["ms_per_pair"]["max"] >= cb["ms_per_pair"]["median"] > 0 and cb["ms_per_evaluation"] > 0
+    assert cb["thread_binding"] == "OMP_PROC_BIND=close OMP_PLACES=cores" and "OMP_PROC_BIND" not in os.environ
+    assert res["T"].shape == (res["pairs"], 4, 4) and len(res["fitness"]) == res["pairs"] == len(res["converged"])
+    from oracle import oracle as orc
+    o = orc.NdtOracle(resolution=1.0)
+    o.set_target(tgt)
+    o.set_source(sources[0])
+    assert np.array_equal(o.align(guesses[0])["T"], res["T"][0])                          # same poses as an in-process run

@@ -141,10 +141,15 @@ def test_cfg4_loop_batch_sharded_api_matches_sequential(oracle_lib):
     r.setInputTarget(tgt)
     o = oracle_lib.NdtOracle(resolution=1.0)
     o.set_target(tgt)
+    n_loose = 0
     for c in range(6):
         assert (dg.last_records[c, 1] > 0.5) == (dc.last_records[c, 1] > 0.5)
         ro, bt, br = ndt_oracle_band(oracle_lib, tgt, sources[c], guesses[c], resolution=1.0)
-        _check_against_band(dg.last_records[c, 4:20].reshape(4, 4), dc.last_records[c, 4:20].reshape(4, 4), bt, br)
+        if not _check_against_band(dg.last_records[c, 4:20].reshape(4, 4), dc.last_records[c, 4:20].reshape(4, 4), bt, br):
+            # the oracle is not reproducible to the gate on this pair: the device must still sit inside twice the oracle's own band
+            et, er = pose_error(dg.last_records[c, 4:20].reshape(4, 4), dc.last_records[c, 4:20].reshape(4, 4))
+            assert et <= 2 * bt + TOL_TRANS and er <= 2 * br + TOL_ROT, (c, et, er, bt, br)
+            n_loose += 1
         # whatever the conditioning, every evaluation along the oracle's own trajectory agrees tightly
         r.setInputSource(sources[c])
         o.set_source(sources[c])
@@ -152,11 +157,10 @@ def test_cfg4_loop_batch_sharded_api_matches_sequential(oracle_lib):
             so, go, Ho = o.derivatives(p)
             sg, gg, Hg = r.ndt_derivatives(p)
             assert abs(so - sg) <= 1e-6 * abs(so) and np.abs(go - gg).max() <= 5e-6 * np.abs(go).max() and np.abs(Ho - Hg).max() <= 5e-6 * np.abs(Ho).max()
-    # the arg-min agrees whenever the two best fitness scores are separated by more than the pose noise can move them
-    fit = np.where(dc.last_records[:, 1] > 0.5, dc.last_records[:, 2], np.inf)
-    order = np.argsort(fit)
-    if np.isfinite(fit[order[0]]) and fit[order[1]] - fit[order[0]] > 0.05 * fit[order[0]]:
-        assert lg is not None and lc is not None and lg.key2.id == lc.key2.id
+    assert n_loose <= 1
+    # the caller-level result: the same loop candidate as the reference's sequential loop, its score to 1e-3 relative
+    assert lg is not None and lc is not None and lg.key2.id == lc.key2.id
+    assert abs(lg.score - lc.score) <= 1e-3 * lc.score
 
 
 def test_committed_goldens_on_the_device():

@@ -106,3 +106,120 @@ def test_group_of_eight_members_with_more_and_fewer_candidates_than_members():
     _same(g.align_batch(sources[:5], guesses[:5]), ref[:5])
     fit = [x["fitness"] if x["converged"] else np.inf for x in ref[:5]]
     assert g.best_index == int(4 - np.argmin(fit[::-1])) and g.best_score == min(fit)
+
+
+# ---- keyframe clouds resident on the group's devices (dgs_group_cloud_*, include/dgs_reg.h) ------------------------------------
+@pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("FAST_GICP", dict(gicp_max_correspondence_distance=2.0))])
+def test_group_of_one_device_with_resident_clouds_equals_align_batch_clouds(batch, method, kw):
+    """group{0}: resident keyframes, records written on the device and exchanged with ncclAllGather == dgs_align_batch_clouds"""
+    from delta_graph_slam_amd.registration import Registration, RegistrationGroup
+    tgt, sources, guesses, _ = batch
+    r = Registration(method, **kw)
+    r.setInputTarget(r.make_cloud(tgt))
+    ref = r.align_batch([r.make_cloud(s) for s in sources], guesses)
+    g = RegistrationGroup(method, devices=[0], **kw)
+    gt = g.make_cloud(tgt)
+    gs = [g.make_cloud(s, owner=i) for i, s in enumerate(sources)]
+    assert gt.copies == 1 and all(c.copies == 1 for c in gs) and len(gs[0]) == sources[0].shape[0]
+    g.setInputTarget(gt)
+    for _ in range(2):                                   # a second tick over the same keyframes: nothing is uploaded again
+        got = g.align_batch(gs, guesses)
+        assert g.last_gather_used_rccl
+        _same(got, ref)
+    fit = [x["fitness"] if x["converged"] else np.inf for x in ref]
+    assert g.best_index == int(len(fit) - 1 - np.argmin(fit[::-1])) and g.best_score == min(fit)
+
+
+def test_group_resident_clouds_owners_replicas_and_promotion(batch):
+    """3 members: candidate keyframes live on their owner (id mod 3), the new keyframe on every member; a keyframe created as a
+    candidate and used as the target later is copied to the other members device-to-device and stays there."""
+    import torch
+    from delta_graph_slam_amd.registration import Registration, RegistrationGroup
+    tgt, sources, guesses, _ = batch
+    r = Registration("NDT_OMP", ndt_resolution=1.0)
+    r.setInputTarget(tgt)
+    ref = r.align_batch(sources, guesses)
+    dev_before = torch.cuda.current_device()
+    g = RegistrationGroup("NDT_OMP", devices=[0, 0, 0], ndt_resolution=1.0)
+    gt = g.make_cloud(tgt)                               # owner None: every member
+    assert gt.copies == 3
+    owned = [g.make_cloud(s, owner=i + 1) for i, s in enumerate(sources)]   # ids 1..7 -> members 1, 2, 0, 1, 2, 0, 1
+    assert all(c.copies == 1 for c in owned)
+    g.setInputTarget(gt)
+    _same(g.align_batch(owned, guesses), ref)
+    empty = g.make_cloud(np.zeros((0, 4), np.float32), owner=0)
+    res = g.align_batch([owned[0], empty, owned[1]], guesses[:3])           # an empty keyframe: per-candidate failure, written on the device
+    assert res[0]["converged"] and res[2]["converged"] and not res[1]["converged"] and res[1]["status"] == 4
+    assert np.array_equal(res[1]["T"], guesses[1]) and np.isnan(res[1]["fitness"])
+    # a candidate keyframe becomes the target: promoted to every member, results equal the single handle's
+    g.setInputTarget(owned[3])
+    assert owned[3].copies == 3
+    r.setInputTarget(sources[3])
+    _same(g.align_batch([owned[0], owned[5]], guesses[[0, 5]]), r.align_batch([sources[0], sources[5]], guesses[[0, 5]]))
+    assert torch.cuda.current_device() == dev_before     # the group leaves the caller's current device alone
+    g.close()
+
+
+def test_loop_detector_caches_keyframes_on_a_group(batch):
+    from delta_graph_slam_amd.loop_detector import KeyFrame, LoopDetector
+    from delta_graph_slam_amd.registration import GroupCloud, Registration, RegistrationGroup
+    tgt, sources, guesses, _ = batch
+    new = KeyFrame(tgt, np.eye(3), 100.0, 100)
+    cands = []
+    for c, G in enumerate(guesses):
+        est = np.eye(3)
+        est[:2, :2] = G[:2, :2]
+        est[:2, 2] = G[:2, 3]
+        cands.append(KeyFrame(sources[c], est, 0.0, c + 1))
+    d1 = LoopDetector({"fitness_score_thresh": 1e9}, registration=Registration("NDT_OMP", ndt_resolution=1.0))
+    d2 = LoopDetector({"fitness_score_thresh": 1e9}, registration=RegistrationGroup("NDT_OMP", devices=[0, 0], ndt_resolution=1.0), cache_clouds=True)
+    l1 = d1.matching(cands, new)
+    for _ in range(2):
+        l2 = d2.matching(cands, new)
+        assert np.array_equal(d1.last_records[:, 1:], d2.last_records[:, 1:])
+        assert (l1 is None) == (l2 is None) and (l1 is None or (l1.key2.id == l2.key2.id and np.array_equal(l1.relative_pose, l2.relative_pose)))
+    assert len(d2._cloud_cache) == 8 and all(isinstance(c, GroupCloud) for c in d2._cloud_cache.values())
+    assert d2._cloud_cache[100].copies == 2 and d2._cloud_cache[3].copies == 1
+
+
+def test_cfg4_at_its_full_candidate_count_256_candidates_over_8_members(oracle_lib):
+    """BASELINE configs[3] at its stated shape on one card: 256 candidate keyframes x 65,536 points against one target, through a
+    dgs_group of 8 members (device 0 listed 8 times: the 8-GPU node's 8 handles / host threads / streams; records gathered on the
+    host because one device cannot hold 8 RCCL ranks), upstream operation order.  Every final transform EQUALS the one the
+    reference's sequential candidate loop (loop_detector.hpp:137-156) produces on the oracle, the chosen candidate is the same, and a
+    257th candidate that repeats the best one wins the tie (loop_detector.hpp:149: later candidate wins).  32 distinct ray-cast
+    scans are re-used round-robin, each use with its own guess (synth.loop_batch)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from delta_graph_slam_amd.registration import RegistrationGroup
+    from tests.helpers import sequential_best
+    N = 256
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=N, n_points=65536, seed=40, distinct_scans=32)
+    o = oracle_lib.NdtOracle(resolution=1.0)
+    o.set_target(tgt)
+    ref = []
+    for c in range(N):                                    # the reference's loop: one candidate after the other
+        o.set_source(sources[c])
+        ref.append(o.align(guesses[c]))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        fit_ref = list(ex.map(lambda c: oracle_lib.fitness_score(tgt, sources[c], ref[c]["T"])[0], range(N)))
+    b_ref, s_ref = sequential_best([x["converged"] for x in ref], fit_ref)
+    assert b_ref >= 0
+    g = RegistrationGroup("NDT_OMP", devices=[0] * 8, ndt_resolution=1.0, ndt_strict_order=1)
+    # resident keyframes (the deployable form): the 32 distinct scans uploaded once, owner = keyframe id; candidate c -> its owner
+    gt = g.make_cloud(tgt)
+    kf = [g.make_cloud(sources[k], owner=k) for k in range(32)]
+    g.setInputTarget(gt)
+    res = g.align_batch([kf[c % 32] for c in range(N)], guesses)
+    for c in range(N):
+        assert res[c]["status"] == 0 and res[c]["converged"] == ref[c]["converged"] and res[c]["iterations"] == ref[c]["iterations"], c
+        assert np.array_equal(res[c]["T"], ref[c]["T"]), c
+        assert abs(res[c]["fitness"] - fit_ref[c]) <= 1e-11 * fit_ref[c], c
+    assert g.best_index == b_ref and abs(g.best_score - s_ref) <= 1e-11 * s_ref
+    # host keyframes (dgs_group_align_batch, candidate c -> member c mod 8) + the tie: the best candidate once more at the end
+    g.setInputTarget(tgt)
+    res2 = g.align_batch(list(sources) + [sources[b_ref]], np.concatenate([guesses, guesses[b_ref:b_ref + 1]]))
+    for c in range(N):
+        assert np.array_equal(res2[c]["T"], res[c]["T"]) and res2[c]["fitness"] == res[c]["fitness"], c
+    assert np.array_equal(res2[N]["T"], res[b_ref]["T"]) and res2[N]["fitness"] == res[b_ref]["fitness"]
+    assert g.best_index == N
+    g.close()

@@ -173,3 +173,20 @@ def test_factory_refuses_the_reference_branches_it_does_not_serve():
             select_registration_method({"registration_method": name})
         with pytest.raises(NotImplementedError):
             Registration(name)
+    # :88-123 names the reference does not know: it warns and then decides on "OMP" alone -- "FOO" and "NDT_FOO" become
+    # pcl::NormalDistributionsTransform (not served), "FOO_OMP" becomes pclomp's NDT (served: reaches dgs_create)
+    for name in ("FOO", "NDT_FOO", "MY_NDT"):
+        with pytest.raises(NotImplementedError):
+            select_registration_method({"registration_method": name})
+
+
+def test_factory_unknown_name_with_omp_falls_to_ndt_omp_like_the_reference(capsys):
+    from delta_graph_slam_amd.registration import DgsError, select_registration_method
+    try:
+        r = select_registration_method({"registration_method": "FOO_OMP", "reg_resolution": 1.5})
+    except DgsError as e:          # no GPU here: the factory got as far as dgs_create for NDT_OMP
+        assert e.status == 2
+    else:
+        assert r.method == "NDT_OMP" and r.params.ndt_resolution == 1.5
+        r.close()
+    assert "unknown registration type(FOO_OMP)" in capsys.readouterr().err

@@ -62,18 +62,35 @@ def test_nn_index_is_exact_at_full_size_in_any_query_order(scans):
 
 
 def _grid_registration(**kw):
-    """A handle with the grid passes of nn_grid.hip enabled (read from the environment at dgs_create)."""
+    """A handle of the EXPERIMENTS build (`make experiments`: libdgs_reg_exp.so) with the grid passes of nn_grid.hip enabled (read
+    from the environment at dgs_create).  The product library does not carry them (measured slower)."""
     import os
+    from delta_graph_slam_amd import _lib as L
     from delta_graph_slam_amd.registration import Registration
     old = os.environ.get("DGS_NN_GRID")
     os.environ["DGS_NN_GRID"] = "1"
     try:
-        return Registration("NDT_OMP", **kw)
+        return Registration("NDT_OMP", lib_path=L.EXPERIMENTS_LIB_PATH, **kw)
     finally:
         if old is None:
             del os.environ["DGS_NN_GRID"]
         else:
             os.environ["DGS_NN_GRID"] = old
+
+
+def test_product_library_ignores_the_experiment_switches():
+    import os
+    from delta_graph_slam_amd.registration import DgsError, Registration
+    os.environ["DGS_NN_GRID"] = "1"
+    os.environ["DGS_NDT_PACK2"] = "1"
+    try:
+        r = Registration("NDT_OMP")
+    finally:
+        del os.environ["DGS_NN_GRID"], os.environ["DGS_NDT_PACK2"]
+    r.setInputTarget(synth.planar_pair(n=4096)[0])
+    with pytest.raises(DgsError) as e:
+        r.nn_fitness_distances(np.ones((4, 4), np.float32))
+    assert e.value.status == 6          # DGS_ERR_UNSUPPORTED: the grid index is not in libdgs_reg.so
 
 
 @pytest.mark.parametrize("kind", ["indoor", "tiny", "line", "offset", "duplicates"])
@@ -272,7 +289,8 @@ def test_packed_fp32_derivative_path_matches_the_default(scans):
     old = os.environ.get("DGS_NDT_PACK2")
     os.environ["DGS_NDT_PACK2"] = "1"
     try:
-        p = Registration("NDT_OMP", ndt_resolution=1.0)
+        from delta_graph_slam_amd import _lib as L
+        p = Registration("NDT_OMP", ndt_resolution=1.0, lib_path=L.EXPERIMENTS_LIB_PATH)   # the kernel lives in the experiments build only
     finally:
         if old is None:
             del os.environ["DGS_NDT_PACK2"]

@@ -15,6 +15,12 @@ from delta_graph_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def shard40(oracle_lib):
+    from tests.helpers import oracle_shard
+    return oracle_shard(oracle_lib, 40)
+
+
 def _reg(mode, **kw):
     from delta_graph_slam_amd.registration import Registration
     kw.setdefault("ndt_resolution", 1.0)
@@ -119,43 +125,20 @@ def test_cfg5_dense_indoor_is_bit_identical(oracle_lib):
     _same_run(r, o.align())
 
 
-def test_cfg4_shard_shape_32_candidates_of_65536_points(oracle_lib):
-    """configs[3]'s per-GPU shard (= bench.py's step): 32 candidates x 65,536 points against one target, yaw / xy guesses
-    perturbed by up to 1 m / 5 deg.  Upstream-order mode: every final transform equals the oracle's, unconditionally.  The
-    default (fast) order is checked beside it: same convergence flags, and the same transform within the north-star tolerance
-    on every pair except those on which the oracle itself moves by more than the tolerance under a perturbation that carries
-    no information (profiles/r02/parity_report.json lists them with the iteration at which the trajectories separate)."""
-    from tests.helpers import TOL_ROT, TOL_TRANS, pose_error
-    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=32, n_points=65536, seed=40, distinct_scans=8)
-    o = oracle_lib.NdtOracle(resolution=1.0)
-    o.set_target(tgt)
-    ref = []
-    for c in range(32):
-        o.set_source(sources[c])
-        ref.append(o.align(guesses[c]))
+def test_cfg4_shard_shape_32_candidates_of_65536_points(oracle_lib, shard40):
+    """configs[3]'s per-GPU shard (= bench.py's step, the same 32 distinct scans and guesses): 32 candidates x 65,536 points against
+    one target, yaw / xy guesses perturbed by up to 1 m / 5 deg.  Upstream-order mode: every final transform equals the oracle's,
+    unconditionally, and so does the caller's arg-min.  (The default order on the same shard: tests/test_parity_gate_gpu.py.)"""
+    tgt, sources, guesses, ref, fit_ref = shard40
     r = _reg(1)
     r.setInputTarget(tgt)
     res = r.align_batch(sources, guesses)
     for c in range(32):
         assert res[c]["converged"] == ref[c]["converged"] and res[c]["iterations"] == ref[c]["iterations"]
         assert np.array_equal(res[c]["T"], ref[c]["T"]), c
-        fo, _, _ = oracle_lib.fitness_score(tgt, sources[c], res[c]["T"])
-        assert abs(res[c]["fitness"] - fo) <= 1e-11 * fo
-    f = _reg(0)
-    f.setInputTarget(tgt)
-    fast = f.align_batch(sources, guesses)
-    from tests.helpers import ndt_oracle_band
-    inside = stable = 0
-    for c in range(32):
-        assert fast[c]["converged"] == ref[c]["converged"]
-        dt, dr = pose_error(fast[c]["T"], ref[c]["T"])
-        ok = dt <= TOL_TRANS and dr <= TOL_ROT
-        inside += int(ok)
-        if not ok:   # then the oracle itself must be outside the tolerance under a perturbation that carries no information
-            _, bt, br = ndt_oracle_band(oracle_lib, tgt, sources[c], guesses[c], resolution=1.0)
-            assert bt > TOL_TRANS or br > TOL_ROT, (c, dt, dr, bt, br)
-            assert dt <= 4 * bt + TOL_TRANS and dr <= 4 * br + TOL_ROT, (c, dt, dr, bt, br)
-    assert inside >= 16
+        assert abs(res[c]["fitness"] - fit_ref[c]) <= 1e-11 * fit_ref[c]
+    from tests.helpers import sequential_best
+    assert sequential_best([x["converged"] for x in res], [x["fitness"] for x in res])[0] == sequential_best([x["converged"] for x in ref], fit_ref)[0]
 
 
 def test_structural_zero_shortcuts_are_bit_identical():
