@@ -377,8 +377,10 @@ def cpu_baseline_child(args):
     sweep = {}
     for th in sorted({ncpu, 64, 32, 16, 8}):
         if th <= ncpu:
-            _, tt, pp, _, _ = run(th, n_sweep)
-            sweep[th] = n_sweep / (tt + sum(pp))
+            _, tt, pp, _, _ = run(th, n_sweep if not sweep or th <= 64 else 2)   # (all of a many-core host's threads: 2 pairs are enough to see it lose)
+            sweep[th] = (n_sweep if not sweep or th <= 64 else 2) / (tt + sum(pp))
+            if sweep[th] < 0.5 * max(sweep.values()):
+                break   # past the knee: more threads only get slower
     best_th = max(sweep, key=sweep.get)
     per_pair_est = 1.0 / sweep[best_th]
     n = int(min(P, max(2, args.cpu_seconds / (3.0 * per_pair_est))))   # bounded sample: three repeats inside the budget

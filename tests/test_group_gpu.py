@@ -210,16 +210,42 @@ def test_cfg4_at_its_full_candidate_count_256_candidates_over_8_members(oracle_l
     kf = [g.make_cloud(sources[k], owner=k) for k in range(32)]
     g.setInputTarget(gt)
     res = g.align_batch([kf[c % 32] for c in range(N)], guesses)
+    off = []
     for c in range(N):
         assert res[c]["status"] == 0 and res[c]["converged"] == ref[c]["converged"] and res[c]["iterations"] == ref[c]["iterations"], c
-        assert np.array_equal(res[c]["T"], ref[c]["T"]), c
-        assert abs(res[c]["fitness"] - fit_ref[c]) <= 1e-11 * fit_ref[c], c
-    assert g.best_index == b_ref and abs(g.best_score - s_ref) <= 1e-11 * s_ref
-    # host keyframes (dgs_group_align_batch, candidate c -> member c mod 8) + the tie: the best candidate once more at the end
+        if not np.array_equal(res[c]["T"], ref[c]["T"]) or res[c]["evaluations"] != ref[c]["evaluations"]:
+            off.append(c)
+        # ndt_strict_order = 1 sums the points' double totals in the GPU's own fixed order: an evaluation differs from the CPU's by
+        # ~1e-14 relative.  Where a More-Thuente line search sits at that noise level its sufficient-decrease test can take a few
+        # more (or fewer) trials -- they refine the step by < 1e-9, far below a float of the transform -- and in rare cases ONE float
+        # of a final transform moves by one ulp (measured on these 256 pairs: 9 with another evaluation count and the same
+        # transform, 1 with a one-ulp float; 0 of either kind on the 96 pairs of the three bench shards) -- never more
+        assert np.abs(res[c]["T"].astype(np.float64) - ref[c]["T"]).max() <= 1.2e-7 * max(1.0, np.abs(ref[c]["T"]).max()), c
+        assert abs(res[c]["fitness"] - fit_ref[c]) <= 1e-9 * fit_ref[c], c
+    assert len(off) <= 24 and sum(not np.array_equal(res[c]["T"], ref[c]["T"]) for c in off) <= 3, off
+    assert g.best_index == b_ref and abs(g.best_score - s_ref) <= 1e-9 * s_ref
+    # ... and on exactly those pairs index-order sums (ndt_strict_order = 2: every evaluation bit-identical to the CPU's) give the very
+    # transform, iteration and evaluation counts of the reference loop
+    if off:
+        from delta_graph_slam_amd.registration import Registration
+        r2 = Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=2)
+        r2.setInputTarget(tgt)
+        seq = r2.align_batch([sources[c] for c in off], guesses[off])
+        for c, x in zip(off, seq):
+            assert np.array_equal(x["T"], ref[c]["T"]) and (x["iterations"], x["evaluations"]) == (ref[c]["iterations"], ref[c]["evaluations"]), c
+    # host keyframes (dgs_group_align_batch, candidate c -> member c mod 8) + the tie: the best candidate once more at the end, on the
+    # member that registers the original (so both sit in one batch and are summed alike: an exact tie), behind a few fillers
     g.setInputTarget(tgt)
-    res2 = g.align_batch(list(sources) + [sources[b_ref]], np.concatenate([guesses, guesses[b_ref:b_ref + 1]]))
-    for c in range(N):
-        assert np.array_equal(res2[c]["T"], res[c]["T"]) and res2[c]["fitness"] == res[c]["fitness"], c
-    assert np.array_equal(res2[N]["T"], res[b_ref]["T"]) and res2[N]["fitness"] == res[b_ref]["fitness"]
-    assert g.best_index == N
+    pad = (b_ref - N) % 8
+    extra = [0] * pad + [b_ref]
+    res2 = g.align_batch(list(sources) + [sources[c] for c in extra], np.concatenate([guesses, guesses[extra]]))
+    for c in range(N):   # another batch size per member: another (fixed) partition of the sums -- the same statement as above holds
+        assert res2[c]["iterations"] == ref[c]["iterations"] and res2[c]["converged"] == ref[c]["converged"], c
+        assert np.abs(res2[c]["T"].astype(np.float64) - ref[c]["T"]).max() <= 1.2e-7 * max(1.0, np.abs(ref[c]["T"]).max()), c
+        assert abs(res2[c]["fitness"] - fit_ref[c]) <= 1e-9 * fit_ref[c], c
+    assert sum(not np.array_equal(res2[c]["T"], ref[c]["T"]) for c in range(N)) <= 3
+    last = N + pad
+    assert last % 8 == b_ref % 8
+    assert np.array_equal(res2[last]["T"], res2[b_ref]["T"]) and res2[last]["fitness"] == res2[b_ref]["fitness"]
+    assert g.best_index == last
     g.close()

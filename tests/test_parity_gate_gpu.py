@@ -5,7 +5,7 @@ every pair, bit for bit (tests/test_strict_gpu.py).  The default order re-associ
 iteration with its loose stop (|step| < 0.01) amplifies that on a few ill-conditioned pairs per shard, exactly where the oracle's own
 answer moves by as much under perturbations that carry no information.  What is asserted here, on the three shards
 ranks 0-2 of `bench.py --gpus N` register (seeds 40 / 1040 / 2040, 32 distinct 65,536-point scans each):
-  * per shard at least (measured - 1) pairs inside the gate: 31 / 30 / 27 measured in round 2;
+  * per shard at least (measured - 1) pairs inside the gate: 30 / 30 / 27 measured (31 on the bench's own guesses for seed 40);
   * every pair outside the gate sits on a pair where the oracle's own band is outside the gate too, and within 2 x that band;
   * over the pairs whose oracle band IS inside the gate, every pair is inside and the RMS is inside;
   * the caller-level result cannot hide behind the band: the fast order picks the SAME best candidate as the reference's
@@ -17,7 +17,7 @@ from tests.helpers import TOL_ROT, TOL_TRANS, oracle_shard, pose_error, sequenti
 
 pytestmark = pytest.mark.gpu
 
-MIN_INSIDE = {40: 30, 1040: 29, 2040: 26}
+MIN_INSIDE = {40: 29, 1040: 29, 2040: 26}     # measured 30 / 30 / 27 (scripts/dbg_gate_bands.py, round 3)
 
 
 @pytest.mark.parametrize("seed", [40, 1040, 2040])
@@ -47,5 +47,5 @@ def test_fast_order_on_a_bench_shard(oracle_lib, seed):
     b_gpu, s_gpu = sequential_best([x["converged"] for x in fast], [x["fitness"] for x in fast])
     assert b_ref >= 0 and b_gpu == b_ref, (seed, b_gpu, b_ref, s_gpu, s_ref)
     assert abs(s_gpu - s_ref) <= 1e-3 * s_ref, (seed, s_gpu, s_ref)
-    for c in range(n):   # and every candidate's score, not only the winner's
-        assert abs(fast[c]["fitness"] - fit_ref[c]) <= 5e-2 * fit_ref[c] + 1e-9, (seed, c, fast[c]["fitness"], fit_ref[c])
+    for c in range(n):   # and every candidate's score, not only the winner's (measured: <= 1e-4 relative on all 96 pairs)
+        assert abs(fast[c]["fitness"] - fit_ref[c]) <= 1e-3 * fit_ref[c], (seed, c, fast[c]["fitness"], fit_ref[c])
