@@ -160,7 +160,7 @@ def main():
             k.cache_id = 1 + (c % distinct)
         reg = RegistrationGroup("NDT_OMP", devices=devices, **reg_kw)
         det = _GroupDetector({"fitness_score_thresh": 1e9}, registration=reg, cache_clouds=True)
-        det.matching(cands, new_kf)   # uploads every keyframe once (KeyFrame::cloud is immutable, keyframe.hpp:51): not a timed step
+        det.matching(cands, new_kf)   # uploads every CANDIDATE keyframe once (KeyFrame::cloud is immutable, keyframe.hpp:51): not a timed step
         prof_reg = reg.member(0)
         collective = "rccl (ncclCommInitAll)" if reg.uses_rccl else "host gather (a device listed twice, or RCCL unavailable)"
         n_dev = G
@@ -226,8 +226,9 @@ def main():
                                % (args.resolution, P, distinct, (min(distinct, P) + 1) * args.points * 16 / 1e6),
                    "pairs_per_gpu": P, "points_per_scan": args.points, "distinct_scans": distinct,
                    "ndt_order": "fast (default dgs_params.ndt_strict_order = 0); see parity_gate for what that means against the reference",
-                   "parallelism": ("one process, %d devices behind the C ABI (dgs_group): candidate c -> member c mod G, keyframes resident on their "
-                                   "owners, records written on the device and all-gathered" % n_dev) if args.group else
+                   "parallelism": ("one process, %d devices behind the C ABI (dgs_group): candidate c -> member c mod G, candidate keyframes resident on "
+                                   "their owners, the new keyframe uploaded to every member inside the step (1 MB per member over PCIe, counted in "
+                                   "the timed region), records written on the device and all-gathered" % n_dev) if args.group else
                                   "candidates sharded one process per GPU, all_gather of result records",
                    "collective_backend": collective, "collective_world_size": n_dev},
     }
@@ -645,7 +646,10 @@ def _GroupDetector(params, registration, cache_clouds):
     class D(LoopDetector):
         def resident(self, keyframe, as_target=False):
             if as_target:
-                return super().resident(keyframe, as_target=True)
+                # The new keyframe arrives from the host and is registered against ONCE (one tick): it is uploaded inside the step and its
+                # voxel model / NN index are built inside the step, as in the one-process-per-GPU form -- nothing derived from the target
+                # is carried over from the previous step.  Only the candidate keyframes (immutable, re-used tick after tick) are resident.
+                return keyframe.cloud
             cid = getattr(keyframe, "cache_id", keyframe.id)
             c = self._cloud_cache.get(cid)
             if c is None:

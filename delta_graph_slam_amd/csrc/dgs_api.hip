@@ -251,6 +251,9 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (kExperiments)   // the product library carries neither the grid index nor the packed-FP32 kernel (measured losers: `make experiments`)
     if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NDT_QUEUE")) h->ndt_queue_mode = std::atoi(e);
+  if (const char* e = std::getenv("DGS_NDT_SCHEDULE")) h->ndt_schedule = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NDT_QUEUE_MIN_PAIRS")) h->ndt_queue_min_pairs = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DGS_NN_KD")) h->nn_kd = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD_ALL")) h->nn_kd_all = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD_MIN_QUERIES")) h->nn_kd_min_queries = std::atoll(e);
@@ -289,7 +292,7 @@ void dgs_destroy(dgs_handle* h) {
   h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->vg_run_keys.release(); h->vg_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
-  h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
+  h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->ndt_queue.release(); h->ndt_ring.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
   h->nn_partials.release(); h->scratch_cloud.release(); h->strict_rows.release(); h->strict_totals.release(); h->tgt_grid.release(); h->aux_grid.release();
   h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_out.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
   h->aux_bvh.keys.release(); h->aux_bvh.keys_alt.release(); h->aux_bvh.vals.release(); h->aux_bvh.vals_alt.release();

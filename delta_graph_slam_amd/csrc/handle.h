@@ -147,6 +147,12 @@ struct dgs_handle {
   dgs::DevBuf<dgs::NdtInit> inits;
   dgs::DevBuf<double> partials;       // [pair][block][kAccumPad]
   dgs::DevBuf<int> done_counter;      // [0] = finished pairs
+  dgs::DevBuf<int> ndt_queue;         // queue kernel: 16 control ints, then one 64-byte line per pair (its queue word)
+  dgs::DevBuf<unsigned char> ndt_ring;   // queue kernel: one 384-byte record slot per pair and round (ndt_align.hip, kQueueSlotBytes)
+  int ndt_ring_rounds = 0;
+  int ndt_queue_mode = 1;             // DGS_NDT_QUEUE=0: one launch per evaluation (fused) instead of the persistent queue kernel
+  bool ndt_schedule = false;          // DGS_NDT_SCHEDULE=1 (tests): the launch-per-evaluation path cuts every round like the queue kernel would
+  int ndt_queue_min_pairs = 2;        // DGS_NDT_QUEUE_MIN_PAIRS: batches smaller than this keep the launch-per-evaluation path
   dgs::DevBuf<int> pair_blocks;       // slices the last derivative launch gave each pair
   dgs::DevBuf<double> strict_rows;    // ndt_strict_order 2: per-point totals, [pair][43][max_n] (column-major per pair)
   dgs::DevBuf<double> strict_totals;  // ndt_strict_order 1/2: [pair][kStrictPad] sums of one evaluation

@@ -64,7 +64,9 @@ __device__ __forceinline__ void neighbour_offset(int k, int& dx, int& dy, int& d
   }
 }
 
-__device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch);
+template <bool QUEUE = false>
+__device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch,
+                                                     NdtPair* hdr_next = nullptr, int need_h_in = -1);
 
 // FUSED = false: derivatives only; ndt_solve_kernel (one workgroup per pair) follows as a second launch.
 // FUSED = true: the workgroup of a pair that finishes LAST (a per-pair ticket) also sums the pair's partial rows in their fixed
@@ -77,6 +79,177 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
 // which its closing workgroup may write during a launch without changing what the other workgroups of that launch see.
 // __launch_bounds__(kBlock, 4) holds the kernel at the derivative loop's 4 waves per SIMD; the optimiser tail (one workgroup per
 // pair and launch) spills what does not fit.
+// ---- the per-point work of computeDerivatives (fast order), shared by the launch-per-evaluation kernel and the queue kernel ----------
+// The angle tables of the evaluation come through an accessor: the pair's record in HBM read with scalar loads (valid across a
+// kernel boundary), or a copy in scalar registers made from coherent loads (inside the persistent queue kernel).
+struct NdtHdrGlobal {
+  const NdtPair& st;
+  __device__ __forceinline__ float J(int k, int c) const { return st.jang[k][c]; }
+  __device__ __forceinline__ float H(int k, int c) const { return st.hang[k][c]; }
+};
+struct NdtHdrRegs {
+  float j[24], h[45];
+  __device__ __forceinline__ float J(int k, int c) const { return j[k * 3 + c]; }
+  __device__ __forceinline__ float H(int k, int c) const { return h[k * 3 + c]; }
+};
+
+template <int SEARCH, class HDR>
+__device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& hdr, const bool need_h, const float4* __restrict__ src, const int n,
+                                               const int first, const int stride, const VoxelGrid& g, const double gd1, const float gd2,
+                                               const int leaf_pow2, double (&acc)[kAccum]) {
+  const float r2 = g.leaf * g.leaf;
+  for (int i = first; i < n; i += stride) {
+    const float4 x = src[i];
+    // pcl::transformPointCloud in float, ((m0 x + m1 y) + m2 z) + m3 with every step rounded (no FMA contraction):
+    // q = x' - mean is a cancellation, so one ulp of x' is ~1e-5 of a point's contribution -- keep x' exact.
+    const float xt0 = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
+    const float xt1 = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
+    const float xt2 = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
+    // getNeighborhoodAtPoint: floor(x / leaf_size); x * (1 / leaf) is the same number when leaf is a power of two
+    const int c0 = (int)floorf(leaf_pow2 ? xt0 * g.inv_leaf : xt0 / g.leaf);
+    const int c1 = (int)floorf(leaf_pow2 ? xt1 * g.inv_leaf : xt1 / g.leaf);
+    const int c2 = (int)floorf(leaf_pow2 ? xt2 * g.inv_leaf : xt2 / g.leaf);
+
+    // ---- gather: voxel ids of the neighbourhood (independent loads, issued together)
+    constexpr int NB = Offsets<SEARCH>::N;
+    int vid[NB];
+    // interior cells (every neighbour inside the grid) need no per-neighbour bounds test: base pointer + fixed offsets
+    const bool interior = c0 > g.min_b[0] && c0 < g.max_b[0] && c1 > g.min_b[1] && c1 < g.max_b[1] && c2 > g.min_b[2] && c2 < g.max_b[2];
+    if (interior) {
+      const int* __restrict__ base = g.cell2vox + ((c0 - g.min_b[0]) + (c1 - g.min_b[1]) * g.mul1 + (c2 - g.min_b[2]) * g.mul2);
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        int dx, dy, dz;
+        neighbour_offset<SEARCH>(k, dx, dy, dz);
+        vid[k] = base[dx + dy * g.mul1 + dz * g.mul2];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        int dx, dy, dz;
+        neighbour_offset<SEARCH>(k, dx, dy, dz);
+        const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
+        const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
+        vid[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+      }
+    }
+
+    // ---- fold the neighbourhood:  A = sum w C,  b = sum w C q,  M = sum w d2 (Cq)(Cq)^T,  score
+    float A[6] = {0, 0, 0, 0, 0, 0}, M[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, sc = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (vid[k] < 0) continue;
+      if (SEARCH == DGS_NDT_KDTREE) {
+        const float4 ce = g.centroid[vid[k]];
+        const float ex = ce.x - xt0, ey = ce.y - xt1, ez = ce.z - xt2;
+        if (!(ex * ex + ey * ey + ez * ez < r2)) continue;
+      }
+      const VoxelRec* __restrict__ rec = g.vox + vid[k];
+      const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);  // three aligned 16-B loads
+      const float4 ra = r4[0], rb = r4[1], rc = r4[2];
+      const double mx = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x));
+      const double my = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z));
+      const double mz = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
+      const float q0 = (float)((double)xt0 - mx), q1 = (float)((double)xt1 - my), q2 = (float)((double)xt2 - mz);
+      const float Cxx = rb.z, Cxy = rb.w, Cxz = rc.x, Cyy = rc.y, Cyz = rc.z, Czz = rc.w;
+      const float u0 = q0 * Cxx + q1 * Cxy + q2 * Cxz;
+      const float u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
+      const float u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
+      float e = expf(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
+      // gauss_d1 is a double upstream: float(double(e) * d1), not e * float(d1) -- the float constant alone would scale score,
+      // gradient and Hessian by (1 + 2.8e-8) at 1 m resolution, which was the whole per-evaluation difference to a CPU run
+      const float score_inc = (float)(-gd1 * (double)e);
+      e = gd2 * e;
+      if (e > 1.f || e < 0.f || e != e) continue;  // upstream "error checking for invalid values"
+      const float w = (float)((double)e * gd1);
+      const float wd = w * gd2;
+      sc += score_inc;
+      any = true;
+      b[0] += w * u0; b[1] += w * u1; b[2] += w * u2;
+      A[0] += w * Cxx; A[1] += w * Cxy; A[2] += w * Cxz; A[3] += w * Cyy; A[4] += w * Cyz; A[5] += w * Czz;
+      M[0] += wd * u0 * u0; M[1] += wd * u0 * u1; M[2] += wd * u0 * u2; M[3] += wd * u1 * u1; M[4] += wd * u1 * u2; M[5] += wd * u2 * u2;
+    }
+    if (!any) continue;
+
+    // ---- project through the point Jacobian (eq. 6.18/6.19): J = [I | J3 J4 J5]
+    float xj[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xj[k] = hdr.J(k, 0) * x.x + hdr.J(k, 1) * x.y + hdr.J(k, 2) * x.z;
+    const float J3[3] = {0.f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
+    acc[0] += (double)sc;
+    acc[1] += (double)b[0];
+    acc[2] += (double)b[1];
+    acc[3] += (double)b[2];
+    acc[4] += (double)(b[1] * J3[1] + b[2] * J3[2]);
+    acc[5] += (double)(b[0] * J4[0] + b[1] * J4[1] + b[2] * J4[2]);
+    acc[6] += (double)(b[0] * J5[0] + b[1] * J5[1] + b[2] * J5[2]);
+    if (need_h) {
+      const float N0 = A[0] - M[0], N1 = A[1] - M[1], N2 = A[2] - M[2], N3 = A[3] - M[3], N4 = A[4] - M[4], N5 = A[5] - M[5];
+      // N * J_k
+      const float n3[3] = {N1 * J3[1] + N2 * J3[2], N3 * J3[1] + N4 * J3[2], N4 * J3[1] + N5 * J3[2]};
+      const float n4[3] = {N0 * J4[0] + N1 * J4[1] + N2 * J4[2], N1 * J4[0] + N3 * J4[1] + N4 * J4[2], N2 * J4[0] + N4 * J4[1] + N5 * J4[2]};
+      const float n5[3] = {N0 * J5[0] + N1 * J5[1] + N2 * J5[2], N1 * J5[0] + N3 * J5[1] + N4 * J5[2], N2 * J5[0] + N4 * J5[1] + N5 * J5[2]};
+      float xh[15];
+#pragma unroll
+      for (int k = 0; k < 15; k++) xh[k] = hdr.H(k, 0) * x.x + hdr.H(k, 1) * x.y + hdr.H(k, 2) * x.z;
+      // b . second derivatives: a=(0,xh0,xh1) b=(0,xh2,xh3) c=(0,xh4,xh5) d=(xh6..8) e=(xh9..11) f=(xh12..14)
+      const float ba = b[1] * xh[0] + b[2] * xh[1];
+      const float bb = b[1] * xh[2] + b[2] * xh[3];
+      const float bc = b[1] * xh[4] + b[2] * xh[5];
+      const float bd = b[0] * xh[6] + b[1] * xh[7] + b[2] * xh[8];
+      const float be = b[0] * xh[9] + b[1] * xh[10] + b[2] * xh[11];
+      const float bf = b[0] * xh[12] + b[1] * xh[13] + b[2] * xh[14];
+      // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+      acc[7] += (double)N0;  acc[8] += (double)N1;  acc[9] += (double)N2;  acc[10] += (double)n3[0]; acc[11] += (double)n4[0]; acc[12] += (double)n5[0];
+      acc[13] += (double)N3; acc[14] += (double)N4; acc[15] += (double)n3[1]; acc[16] += (double)n4[1]; acc[17] += (double)n5[1];
+      acc[18] += (double)N5; acc[19] += (double)n3[2]; acc[20] += (double)n4[2]; acc[21] += (double)n5[2];
+      acc[22] += (double)(J3[1] * n3[1] + J3[2] * n3[2] + ba);
+      acc[23] += (double)(J3[1] * n4[1] + J3[2] * n4[2] + bb);
+      acc[24] += (double)(J3[1] * n5[1] + J3[2] * n5[2] + bc);
+      acc[25] += (double)(J4[0] * n4[0] + J4[1] * n4[1] + J4[2] * n4[2] + bd);
+      acc[26] += (double)(J4[0] * n5[0] + J4[1] * n5[1] + J4[2] * n5[2] + be);
+      acc[27] += (double)(J5[0] * n5[0] + J5[1] * n5[1] + J5[2] * n5[2] + bf);
+    }
+  }
+}
+
+// Block reduction of the 28 per-thread totals into one row.  A DPP butterfly over 28 doubles costs ~900 wave-instructions; instead
+// every wave transposes through LDS, 14 values at a time: lane l stores value k at row k (stride 65 doubles: conflict-free both
+// ways), then lane k adds the 64 entries of row k in lane order (fixed order -> reproducible).  ~290 wave-instructions.
+// COHERENT: the row is handed over inside the launch (common.h, "in-launch hand-off"): write-through stores.
+template <bool COHERENT>
+__device__ __forceinline__ void ndt_block_row(const double (&acc)[kAccum], double* __restrict__ row_of_slice) {
+  constexpr int HALF = kAccum / 2, RS = 65;
+  __shared__ double tr[kBlock / kWave][HALF * RS];
+  __shared__ double sm[kBlock / kWave][kAccumPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* my = tr[wave];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int k = 0; k < HALF; k++) my[k * RS + lane] = acc[h * HALF + k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+    if (lane < HALF) {
+      double v = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 64; j++) v += my[lane * RS + j];
+      sm[wave][h * HALF + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccumPad) {
+    double v = 0.0;
+    if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    double* row = row_of_slice + threadIdx.x;
+    if (COHERENT) handoff_store_row(row, v);   // write-through (sc1): no release fence needed
+    else *row = v;
+  }
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f affine_row_rn2(float m0, float m1, float m2, float m3, v2f x, v2f y, v2f z) {
 #pragma clang fp contract(off)
@@ -137,7 +310,6 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
 #pragma unroll
   for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
 
-  const float r2 = g.leaf * g.leaf;
   if constexpr (PACK2 && SEARCH == DGS_NDT_DIRECT7) {
     constexpr int NB = 7;
     const int stride = blocks_per_pair * kBlock;
@@ -252,154 +424,10 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
     }
   } else
   {
-  for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
-    const float4 x = src[i];
-    // pcl::transformPointCloud in float, ((m0 x + m1 y) + m2 z) + m3 with every step rounded (no FMA contraction):
-    // q = x' - mean is a cancellation, so one ulp of x' is ~1e-5 of a point's contribution -- keep x' exact.
-    const float xt0 = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
-    const float xt1 = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
-    const float xt2 = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
-    // getNeighborhoodAtPoint: floor(x / leaf_size); x * (1 / leaf) is the same number when leaf is a power of two
-    const int c0 = (int)floorf(leaf_pow2 ? xt0 * g.inv_leaf : xt0 / g.leaf);
-    const int c1 = (int)floorf(leaf_pow2 ? xt1 * g.inv_leaf : xt1 / g.leaf);
-    const int c2 = (int)floorf(leaf_pow2 ? xt2 * g.inv_leaf : xt2 / g.leaf);
-
-    // ---- gather: voxel ids of the neighbourhood (independent loads, issued together)
-    constexpr int NB = Offsets<SEARCH>::N;
-    int vid[NB];
-    // interior cells (every neighbour inside the grid) need no per-neighbour bounds test: base pointer + fixed offsets
-    const bool interior = c0 > g.min_b[0] && c0 < g.max_b[0] && c1 > g.min_b[1] && c1 < g.max_b[1] && c2 > g.min_b[2] && c2 < g.max_b[2];
-    if (interior) {
-      const int* __restrict__ base = g.cell2vox + ((c0 - g.min_b[0]) + (c1 - g.min_b[1]) * g.mul1 + (c2 - g.min_b[2]) * g.mul2);
-#pragma unroll
-      for (int k = 0; k < NB; k++) {
-        int dx, dy, dz;
-        neighbour_offset<SEARCH>(k, dx, dy, dz);
-        vid[k] = base[dx + dy * g.mul1 + dz * g.mul2];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NB; k++) {
-        int dx, dy, dz;
-        neighbour_offset<SEARCH>(k, dx, dy, dz);
-        const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
-        const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
-        vid[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
-      }
-    }
-
-    // ---- fold the neighbourhood:  A = sum w C,  b = sum w C q,  M = sum w d2 (Cq)(Cq)^T,  score
-    float A[6] = {0, 0, 0, 0, 0, 0}, M[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, sc = 0.f;
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      if (vid[k] < 0) continue;
-      if (SEARCH == DGS_NDT_KDTREE) {
-        const float4 ce = g.centroid[vid[k]];
-        const float ex = ce.x - xt0, ey = ce.y - xt1, ez = ce.z - xt2;
-        if (!(ex * ex + ey * ey + ez * ez < r2)) continue;
-      }
-      const VoxelRec* __restrict__ rec = g.vox + vid[k];
-      const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);  // three aligned 16-B loads
-      const float4 ra = r4[0], rb = r4[1], rc = r4[2];
-      const double mx = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x));
-      const double my = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z));
-      const double mz = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
-      const float q0 = (float)((double)xt0 - mx), q1 = (float)((double)xt1 - my), q2 = (float)((double)xt2 - mz);
-      const float Cxx = rb.z, Cxy = rb.w, Cxz = rc.x, Cyy = rc.y, Cyz = rc.z, Czz = rc.w;
-      const float u0 = q0 * Cxx + q1 * Cxy + q2 * Cxz;
-      const float u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
-      const float u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
-      float e = expf(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
-      // gauss_d1 is a double upstream: float(double(e) * d1), not e * float(d1) -- the float constant alone would scale score,
-      // gradient and Hessian by (1 + 2.8e-8) at 1 m resolution, which was the whole per-evaluation difference to a CPU run
-      const float score_inc = (float)(-gd1 * (double)e);
-      e = gd2 * e;
-      if (e > 1.f || e < 0.f || e != e) continue;  // upstream "error checking for invalid values"
-      const float w = (float)((double)e * gd1);
-      const float wd = w * gd2;
-      sc += score_inc;
-      any = true;
-      b[0] += w * u0; b[1] += w * u1; b[2] += w * u2;
-      A[0] += w * Cxx; A[1] += w * Cxy; A[2] += w * Cxz; A[3] += w * Cyy; A[4] += w * Cyz; A[5] += w * Czz;
-      M[0] += wd * u0 * u0; M[1] += wd * u0 * u1; M[2] += wd * u0 * u2; M[3] += wd * u1 * u1; M[4] += wd * u1 * u2; M[5] += wd * u2 * u2;
-    }
-    if (!any) continue;
-
-    // ---- project through the point Jacobian (eq. 6.18/6.19): J = [I | J3 J4 J5]
-    float xj[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) xj[k] = st.jang[k][0] * x.x + st.jang[k][1] * x.y + st.jang[k][2] * x.z;
-    const float J3[3] = {0.f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
-    acc[0] += (double)sc;
-    acc[1] += (double)b[0];
-    acc[2] += (double)b[1];
-    acc[3] += (double)b[2];
-    acc[4] += (double)(b[1] * J3[1] + b[2] * J3[2]);
-    acc[5] += (double)(b[0] * J4[0] + b[1] * J4[1] + b[2] * J4[2]);
-    acc[6] += (double)(b[0] * J5[0] + b[1] * J5[1] + b[2] * J5[2]);
-    if (need_h) {
-      const float N0 = A[0] - M[0], N1 = A[1] - M[1], N2 = A[2] - M[2], N3 = A[3] - M[3], N4 = A[4] - M[4], N5 = A[5] - M[5];
-      // N * J_k
-      const float n3[3] = {N1 * J3[1] + N2 * J3[2], N3 * J3[1] + N4 * J3[2], N4 * J3[1] + N5 * J3[2]};
-      const float n4[3] = {N0 * J4[0] + N1 * J4[1] + N2 * J4[2], N1 * J4[0] + N3 * J4[1] + N4 * J4[2], N2 * J4[0] + N4 * J4[1] + N5 * J4[2]};
-      const float n5[3] = {N0 * J5[0] + N1 * J5[1] + N2 * J5[2], N1 * J5[0] + N3 * J5[1] + N4 * J5[2], N2 * J5[0] + N4 * J5[1] + N5 * J5[2]};
-      float xh[15];
-#pragma unroll
-      for (int k = 0; k < 15; k++) xh[k] = st.hang[k][0] * x.x + st.hang[k][1] * x.y + st.hang[k][2] * x.z;
-      // b . second derivatives: a=(0,xh0,xh1) b=(0,xh2,xh3) c=(0,xh4,xh5) d=(xh6..8) e=(xh9..11) f=(xh12..14)
-      const float ba = b[1] * xh[0] + b[2] * xh[1];
-      const float bb = b[1] * xh[2] + b[2] * xh[3];
-      const float bc = b[1] * xh[4] + b[2] * xh[5];
-      const float bd = b[0] * xh[6] + b[1] * xh[7] + b[2] * xh[8];
-      const float be = b[0] * xh[9] + b[1] * xh[10] + b[2] * xh[11];
-      const float bf = b[0] * xh[12] + b[1] * xh[13] + b[2] * xh[14];
-      // upper triangle, row-major: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
-      acc[7] += (double)N0;  acc[8] += (double)N1;  acc[9] += (double)N2;  acc[10] += (double)n3[0]; acc[11] += (double)n4[0]; acc[12] += (double)n5[0];
-      acc[13] += (double)N3; acc[14] += (double)N4; acc[15] += (double)n3[1]; acc[16] += (double)n4[1]; acc[17] += (double)n5[1];
-      acc[18] += (double)N5; acc[19] += (double)n3[2]; acc[20] += (double)n4[2]; acc[21] += (double)n5[2];
-      acc[22] += (double)(J3[1] * n3[1] + J3[2] * n3[2] + ba);
-      acc[23] += (double)(J3[1] * n4[1] + J3[2] * n4[2] + bb);
-      acc[24] += (double)(J3[1] * n5[1] + J3[2] * n5[2] + bc);
-      acc[25] += (double)(J4[0] * n4[0] + J4[1] * n4[1] + J4[2] * n4[2] + bd);
-      acc[26] += (double)(J4[0] * n5[0] + J4[1] * n5[1] + J4[2] * n5[2] + be);
-      acc[27] += (double)(J5[0] * n5[0] + J5[1] * n5[1] + J5[2] * n5[2] + bf);
-    }
+    ndt_point_loop<SEARCH>(T, NdtHdrGlobal{st}, need_h, src, n, slice * kBlock + (int)threadIdx.x, blocks_per_pair * kBlock, g, gd1, gd2, leaf_pow2, acc);
   }
 
-  }
-
-  // ---- block reduction.  A DPP butterfly over 28 doubles costs ~900 wave-instructions; instead every wave transposes
-  // through LDS, 14 values at a time: lane l stores value k at row k (stride 65 doubles: conflict-free both ways), then
-  // lane k adds the 64 entries of row k in lane order (fixed order -> reproducible).  ~290 wave-instructions.
-  constexpr int HALF = kAccum / 2, RS = 65;
-  __shared__ double tr[kBlock / kWave][HALF * RS];
-  __shared__ double sm[kBlock / kWave][kAccumPad];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* my = tr[wave];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-#pragma unroll
-    for (int k = 0; k < HALF; k++) my[k * RS + lane] = acc[h * HALF + k];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
-    if (lane < HALF) {
-      double v = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < 64; j++) v += my[lane * RS + j];
-      sm[wave][h * HALF + lane] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-  }
-  __syncthreads();
-  if (threadIdx.x < kAccumPad) {
-    double v = 0.0;
-    if (threadIdx.x < kAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    double* row = partials + ((size_t)pair * cap_blocks + slice) * kAccumPad + threadIdx.x;
-    if (FUSED) handoff_store_row(row, v);   // write-through (sc1): no release fence needed (common.h, "in-launch hand-off")
-    else *row = v;
-  }
+  ndt_block_row<FUSED>(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
   if (!FUSED) return;
   // ---- publish this slice's row, take a ticket; the workgroup that takes the pair's last ticket closes the evaluation
   __shared__ int s_last;
@@ -685,8 +713,22 @@ __device__ __forceinline__ void trig6(const double* ang, double* sn, double* cs)
   }
 }
 
-template <bool WAVE>
-__device__ __forceinline__ void write_evaluation(NdtPair* st, NdtSolver& s, const NdtConsts& c, const double* x, int need_hessian, bool write_T, bool writer) {
+template <bool COH>
+__device__ __forceinline__ void hdr_put(float* p, float v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ void hdr_put_int(int* p, int v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// `hdr` receives what the derivative pass of the evaluation reads (transform, angle tables, need_hessian): the pair's own record, or -- in
+// the queue kernel -- the record slot of the pair's NEXT round; final_T always goes to the pair's record `st`.
+// COH: read by other workgroups of the SAME launch (queue kernel): every word is written through (agent-scope stores)
+template <bool WAVE, bool COH = false>
+__device__ __forceinline__ void write_evaluation(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, const double* x, int need_hessian, bool write_T, bool writer) {
   // angles 0..2: the FLOAT-rounded pose angles (transform entries), 3..5: the double pose angles (derivative tables)
   const double ang[6] = {(double)(float)x[3], (double)(float)x[4], (double)(float)x[5], x[3], x[4], x[5]};
   double sn[6], cs[6];
@@ -702,14 +744,14 @@ __device__ __forceinline__ void write_evaluation(NdtPair* st, NdtSolver& s, cons
     const float r20 = sub_rn(mul_rn(sx, sz), mul_rn(mul_rn(cx, sy), cz)), r21 = add_rn(mul_rn(sx, cz), mul_rn(mul_rn(cx, sy), sz)), r22 = mul_rn(cx, cy);
     const float t0 = (float)x[0], t1 = (float)x[1], t2 = (float)x[2];
     if (writer) {
-      st->T[0] = r00; st->T[1] = r01; st->T[2] = r02; st->T[3] = t0;
-      st->T[4] = r10; st->T[5] = r11; st->T[6] = r12; st->T[7] = t1;
-      st->T[8] = r20; st->T[9] = r21; st->T[10] = r22; st->T[11] = t2;
+      hdr_put<COH>(&hdr->T[0], r00); hdr_put<COH>(&hdr->T[1], r01); hdr_put<COH>(&hdr->T[2], r02); hdr_put<COH>(&hdr->T[3], t0);
+      hdr_put<COH>(&hdr->T[4], r10); hdr_put<COH>(&hdr->T[5], r11); hdr_put<COH>(&hdr->T[6], r12); hdr_put<COH>(&hdr->T[7], t1);
+      hdr_put<COH>(&hdr->T[8], r20); hdr_put<COH>(&hdr->T[9], r21); hdr_put<COH>(&hdr->T[10], r22); hdr_put<COH>(&hdr->T[11], t2);
       float* F = st->final_T;  // column-major
-      F[0] = r00; F[1] = r10; F[2] = r20; F[3] = 0.f;
-      F[4] = r01; F[5] = r11; F[6] = r21; F[7] = 0.f;
-      F[8] = r02; F[9] = r12; F[10] = r22; F[11] = 0.f;
-      F[12] = t0; F[13] = t1; F[14] = t2; F[15] = 1.f;
+      hdr_put<COH>(&F[0], r00); hdr_put<COH>(&F[1], r10); hdr_put<COH>(&F[2], r20); hdr_put<COH>(&F[3], 0.f);
+      hdr_put<COH>(&F[4], r01); hdr_put<COH>(&F[5], r11); hdr_put<COH>(&F[6], r21); hdr_put<COH>(&F[7], 0.f);
+      hdr_put<COH>(&F[8], r02); hdr_put<COH>(&F[9], r12); hdr_put<COH>(&F[10], r22); hdr_put<COH>(&F[11], 0.f);
+      hdr_put<COH>(&F[12], t0); hdr_put<COH>(&F[13], t1); hdr_put<COH>(&F[14], t2); hdr_put<COH>(&F[15], 1.f);
     }
   }
   double cx, cy, cz, sx, sy, sz;
@@ -717,35 +759,35 @@ __device__ __forceinline__ void write_evaluation(NdtPair* st, NdtSolver& s, cons
   if (fabs(x[4]) < 10e-5) { cy = 1.0; sy = 0.0; } else { cy = cs[4]; sy = sn[4]; }
   if (fabs(x[5]) < 10e-5) { cz = 1.0; sz = 0.0; } else { cz = cs[5]; sz = sn[5]; }
   if (writer) {
-    float (*J)[3] = st->jang;
-    J[0][0] = (float)(-sx * sz + cx * sy * cz); J[0][1] = (float)(-sx * cz - cx * sy * sz); J[0][2] = (float)(-cx * cy);
-    J[1][0] = (float)(cx * sz + sx * sy * cz);  J[1][1] = (float)(cx * cz - sx * sy * sz);  J[1][2] = (float)(-sx * cy);
-    J[2][0] = (float)(-sy * cz);                J[2][1] = (float)(sy * sz);                 J[2][2] = (float)(cy);
-    J[3][0] = (float)(sx * cy * cz);            J[3][1] = (float)(-sx * cy * sz);           J[3][2] = (float)(sx * sy);
-    J[4][0] = (float)(-cx * cy * cz);           J[4][1] = (float)(cx * cy * sz);            J[4][2] = (float)(-cx * sy);
-    J[5][0] = (float)(-cy * sz);                J[5][1] = (float)(-cy * cz);                J[5][2] = 0.f;
-    J[6][0] = (float)(cx * cz - sx * sy * sz);  J[6][1] = (float)(-cx * sz - sx * sy * cz); J[6][2] = 0.f;
-    J[7][0] = (float)(sx * cz + cx * sy * sz);  J[7][1] = (float)(cx * sy * cz - sx * sz);  J[7][2] = 0.f;
-    float (*H)[3] = st->hang;
+    float (*J)[3] = hdr->jang;
+    hdr_put<COH>(&J[0][0], (float)(-sx * sz + cx * sy * cz)); hdr_put<COH>(&J[0][1], (float)(-sx * cz - cx * sy * sz)); hdr_put<COH>(&J[0][2], (float)(-cx * cy));
+    hdr_put<COH>(&J[1][0], (float)(cx * sz + sx * sy * cz));  hdr_put<COH>(&J[1][1], (float)(cx * cz - sx * sy * sz));  hdr_put<COH>(&J[1][2], (float)(-sx * cy));
+    hdr_put<COH>(&J[2][0], (float)(-sy * cz));                hdr_put<COH>(&J[2][1], (float)(sy * sz));                 hdr_put<COH>(&J[2][2], (float)(cy));
+    hdr_put<COH>(&J[3][0], (float)(sx * cy * cz));            hdr_put<COH>(&J[3][1], (float)(-sx * cy * sz));           hdr_put<COH>(&J[3][2], (float)(sx * sy));
+    hdr_put<COH>(&J[4][0], (float)(-cx * cy * cz));           hdr_put<COH>(&J[4][1], (float)(cx * cy * sz));            hdr_put<COH>(&J[4][2], (float)(-cx * sy));
+    hdr_put<COH>(&J[5][0], (float)(-cy * sz));                hdr_put<COH>(&J[5][1], (float)(-cy * cz));                hdr_put<COH>(&J[5][2], 0.f);
+    hdr_put<COH>(&J[6][0], (float)(cx * cz - sx * sy * sz));  hdr_put<COH>(&J[6][1], (float)(-cx * sz - sx * sy * cz)); hdr_put<COH>(&J[6][2], 0.f);
+    hdr_put<COH>(&J[7][0], (float)(sx * cz + cx * sy * sz));  hdr_put<COH>(&J[7][1], (float)(cx * sy * cz - sx * sz));  hdr_put<COH>(&J[7][2], 0.f);
+    float (*H)[3] = hdr->hang;
     if (need_hessian) {  // a score + gradient evaluation (More-Thuente trial) never reads the second-derivative tables
-    H[0][0] = (float)(-cx * sz - sx * sy * cz); H[0][1] = (float)(-cx * cz + sx * sy * sz); H[0][2] = (float)(sx * cy);    // a2
-    H[1][0] = (float)(-sx * sz + cx * sy * cz); H[1][1] = (float)(-cx * sy * sz - sx * cz); H[1][2] = (float)(-cx * cy);   // a3
-    H[2][0] = (float)(cx * cy * cz);            H[2][1] = (float)(-cx * cy * sz);           H[2][2] = (float)(cx * sy);    // b2
-    H[3][0] = (float)(sx * cy * cz);            H[3][1] = (float)(-sx * cy * sz);           H[3][2] = (float)(sx * sy);    // b3
-    H[4][0] = (float)(-sx * cz - cx * sy * sz); H[4][1] = (float)(sx * sz - cx * sy * cz);  H[4][2] = 0.f;                 // c2
-    H[5][0] = (float)(cx * cz - sx * sy * sz);  H[5][1] = (float)(-sx * sy * cz - cx * sz); H[5][2] = 0.f;                 // c3
+    hdr_put<COH>(&H[0][0], (float)(-cx * sz - sx * sy * cz)); hdr_put<COH>(&H[0][1], (float)(-cx * cz + sx * sy * sz)); hdr_put<COH>(&H[0][2], (float)(sx * cy));    // a2
+    hdr_put<COH>(&H[1][0], (float)(-sx * sz + cx * sy * cz)); hdr_put<COH>(&H[1][1], (float)(-cx * sy * sz - sx * cz)); hdr_put<COH>(&H[1][2], (float)(-cx * cy));   // a3
+    hdr_put<COH>(&H[2][0], (float)(cx * cy * cz));            hdr_put<COH>(&H[2][1], (float)(-cx * cy * sz));           hdr_put<COH>(&H[2][2], (float)(cx * sy));    // b2
+    hdr_put<COH>(&H[3][0], (float)(sx * cy * cz));            hdr_put<COH>(&H[3][1], (float)(-sx * cy * sz));           hdr_put<COH>(&H[3][2], (float)(sx * sy));    // b3
+    hdr_put<COH>(&H[4][0], (float)(-sx * cz - cx * sy * sz)); hdr_put<COH>(&H[4][1], (float)(sx * sz - cx * sy * cz));  hdr_put<COH>(&H[4][2], 0.f);                 // c2
+    hdr_put<COH>(&H[5][0], (float)(cx * cz - sx * sy * sz));  hdr_put<COH>(&H[5][1], (float)(-sx * sy * cz - cx * sz)); hdr_put<COH>(&H[5][2], 0.f);                 // c3
     // d1: upstream PCL / ndt_omp carry +sy in the z slot; the exact second derivative is -sy (dgs_params.ndt_fix_hessian_d1)
-    H[6][0] = (float)(-cy * cz);                H[6][1] = (float)(cy * sz);                 H[6][2] = (float)(c.fix_hessian_d1 ? -sy : sy);
-    H[7][0] = (float)(-sx * sy * cz);           H[7][1] = (float)(sx * sy * sz);            H[7][2] = (float)(sx * cy);    // d2
-    H[8][0] = (float)(cx * sy * cz);            H[8][1] = (float)(-cx * sy * sz);           H[8][2] = (float)(-cx * cy);   // d3
-    H[9][0] = (float)(sy * sz);                 H[9][1] = (float)(sy * cz);                 H[9][2] = 0.f;                 // e1
-    H[10][0] = (float)(-sx * cy * sz);          H[10][1] = (float)(-sx * cy * cz);          H[10][2] = 0.f;                // e2
-    H[11][0] = (float)(cx * cy * sz);           H[11][1] = (float)(cx * cy * cz);           H[11][2] = 0.f;                // e3
-    H[12][0] = (float)(-cy * cz);               H[12][1] = (float)(cy * sz);                H[12][2] = 0.f;                // f1
-    H[13][0] = (float)(-cx * sz - sx * sy * cz); H[13][1] = (float)(-cx * cz + sx * sy * sz); H[13][2] = 0.f;              // f2
-    H[14][0] = (float)(-sx * sz + cx * sy * cz); H[14][1] = (float)(-cx * sy * sz - sx * cz); H[14][2] = 0.f;              // f3
+    hdr_put<COH>(&H[6][0], (float)(-cy * cz));                hdr_put<COH>(&H[6][1], (float)(cy * sz));                 hdr_put<COH>(&H[6][2], (float)(c.fix_hessian_d1 ? -sy : sy));
+    hdr_put<COH>(&H[7][0], (float)(-sx * sy * cz));           hdr_put<COH>(&H[7][1], (float)(sx * sy * sz));            hdr_put<COH>(&H[7][2], (float)(sx * cy));    // d2
+    hdr_put<COH>(&H[8][0], (float)(cx * sy * cz));            hdr_put<COH>(&H[8][1], (float)(-cx * sy * sz));           hdr_put<COH>(&H[8][2], (float)(-cx * cy));   // d3
+    hdr_put<COH>(&H[9][0], (float)(sy * sz));                 hdr_put<COH>(&H[9][1], (float)(sy * cz));                 hdr_put<COH>(&H[9][2], 0.f);                 // e1
+    hdr_put<COH>(&H[10][0], (float)(-sx * cy * sz));          hdr_put<COH>(&H[10][1], (float)(-sx * cy * cz));          hdr_put<COH>(&H[10][2], 0.f);                // e2
+    hdr_put<COH>(&H[11][0], (float)(cx * cy * sz));           hdr_put<COH>(&H[11][1], (float)(cx * cy * cz));           hdr_put<COH>(&H[11][2], 0.f);                // e3
+    hdr_put<COH>(&H[12][0], (float)(-cy * cz));               hdr_put<COH>(&H[12][1], (float)(cy * sz));                hdr_put<COH>(&H[12][2], 0.f);                // f1
+    hdr_put<COH>(&H[13][0], (float)(-cx * sz - sx * sy * cz)); hdr_put<COH>(&H[13][1], (float)(-cx * cz + sx * sy * sz)); hdr_put<COH>(&H[13][2], 0.f);              // f2
+    hdr_put<COH>(&H[14][0], (float)(-sx * sz + cx * sy * cz)); hdr_put<COH>(&H[14][1], (float)(-cx * sy * sz - sx * cz)); hdr_put<COH>(&H[14][2], 0.f);              // f3
     }
-    st->need_hessian = need_hessian;
+    hdr_put_int<COH>(&hdr->need_hessian, need_hessian);
   }
 #pragma unroll
   for (int k = 0; k < 6; k++) s.x_t[k] = x[k];
@@ -805,8 +847,8 @@ __device__ inline double dot6(const double* a, const double* b) {
 
 // Starts one outer iteration from (score, grad, hess) at s.p.  Returns true when an evaluation was queued,
 // false when the iteration finished without one (zero step) or the registration ended.
-template <bool SVD_REGS>
-__device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
+template <bool SVD_REGS, bool COH = false>
+__device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer) {
   double neg_g[6], delta[6], rc;
 #pragma unroll
   for (int k = 0; k < 6; k++) neg_g[k] = -s.grad[k];
@@ -858,7 +900,7 @@ __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtSolver& s, const
 #ifdef DGS_CLOSE_STAMPS
   if (threadIdx.x == 0 && st->s.nr_iterations == 1) st->traj[kTrajCap - 2][1] = (double)wall_clock64();
 #endif
-  write_evaluation<true>(st, s, c, x, 1, true, writer);
+  write_evaluation<true, COH>(st, hdr, s, c, x, 1, true, writer);
 #ifdef DGS_CLOSE_STAMPS
   if (threadIdx.x == 0 && st->s.nr_iterations == 1) st->traj[kTrajCap - 2][2] = (double)wall_clock64();
 #endif
@@ -890,22 +932,23 @@ __device__ inline bool mt_keep_going(const NdtSolver& s, const NdtConsts& c, dou
   return !s.interval_converged && s.step_iterations < c.mt_max_step_iterations && !(psi_t <= 0 && d_phi_t <= -kNu * s.d_phi_0);
 }
 
-__device__ __forceinline__ void queue_trial(NdtPair* st, NdtSolver& s, const NdtConsts& c, double a_t, bool writer) {
+template <bool COH = false>
+__device__ __forceinline__ void queue_trial(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, double a_t, bool writer) {
   const double step_max = c.step_size, step_min = c.trans_eps / 2;
   a_t = fmax(fmin(a_t, step_max), step_min);
   s.a_t = a_t;
   double x[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) x[k] = s.p[k] + s.dir[k] * a_t;
-  write_evaluation<true>(st, s, c, x, 0, true, writer);
+  write_evaluation<true, COH>(st, hdr, s, c, x, 0, true, writer);
   s.phase = PH_MT_TRIAL;
 }
 
 // Consumes one evaluation result (already stored in s.score/grad/hess) and advances the state machine until
 // the next evaluation is queued or the registration is finished.  Executed by all lanes of one wave in lock step.
 // SVD_REGS: the stand-alone solve launch of the validation modes keeps the SVD workspace in registers (solve6.h)
-template <bool SVD_REGS = false>
-__device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const NdtConsts& c, bool writer) {
+template <bool SVD_REGS = false, bool COH = false>
+__device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer) {
   s.evaluations++;
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
   switch (s.phase) {
@@ -937,14 +980,14 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const Ndt
       if (mt_keep_going(s, c, psi_t, d_phi_t)) {
         const double a_n = s.open_interval ? mt_trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, psi_t, d_psi_t)
                                            : mt_trial_value(s.a_l, s.f_l, s.g_l, s.a_u, s.f_u, s.g_u, s.a_t, phi_t, d_phi_t);
-        queue_trial(st, s, c, a_n, writer);
+        queue_trial<COH>(st, hdr, s, c, a_n, writer);
         return;
       }
       if (s.step_iterations) {  // computeHessian at the accepted point
         double x[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) x[k] = s.x_t[k];
-        write_evaluation<true>(st, s, c, x, 1, false, writer);
+        write_evaluation<true, COH>(st, hdr, s, c, x, 1, false, writer);
         s.phase = PH_MT_HESSIAN;
         return;
       }
@@ -960,7 +1003,7 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const Ndt
     if (iteration_open) {
       if (end_iteration(st, s, c, writer)) return;
     }
-    if (begin_iteration<SVD_REGS>(st, s, c, writer)) return;  // evaluation queued
+    if (begin_iteration<SVD_REGS, COH>(st, hdr, s, c, writer)) return;  // evaluation queued
     if (s.phase == PH_DONE) return;
     iteration_open = true;                          // zero-step iteration: close it and try again
   }
@@ -975,7 +1018,12 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtSolver& s, const Ndt
 #else
 #define CLOSE_STAMP(k)
 #endif
-__device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch) {
+// QUEUE: called inside the persistent queue kernel -- the pair's record was written by another workgroup of the SAME launch and will be
+// read by others: coherent (agent-scope) loads and write-through stores for every word of it.  Returns (to the closing wave) whether
+// the registration has ended.
+template <bool QUEUE>
+__device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch,
+                                                     NdtPair* hdr_next, int need_h_in) {
   CLOSE_STAMP(0)
   __shared__ NdtSolver s_lds;   // the optimiser state lives in LDS: a register copy costs ~150 VGPRs
   NdtSolver& s = s_lds;
@@ -985,8 +1033,9 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
   static_assert(sizeof(NdtSolver) % 8 == 0 && sizeof(NdtSolver) / 8 <= kBlock, "state words");
   constexpr int kWords = (int)(sizeof(NdtSolver) / 8);
   double word = 0.0;
-  if (threadIdx.x < kWords) word = reinterpret_cast<const double*>(&st->s)[threadIdx.x];
-  const int need_h = st->need_hessian;
+  if (threadIdx.x < kWords) word = QUEUE ? __hip_atomic_load(reinterpret_cast<const double*>(&st->s) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : reinterpret_cast<const double*>(&st->s)[threadIdx.x];
+  const int need_h = need_h_in >= 0 ? need_h_in : st->need_hessian;   // queue kernel: the flag of the round being closed comes from its record slot
   // ---- finish the reduction: 8 strided groups x 32 columns, fixed order
   __shared__ double tot[kAccumPad];
   __shared__ double sm[kBlock / kAccumPad][kAccumPad];
@@ -1017,7 +1066,7 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
   }
   __syncthreads();
   CLOSE_STAMP(1)
-  if (threadIdx.x >= kWave) return;
+  if (threadIdx.x >= kWave) return false;
   // ---- one wave advances the optimiser: every lane computes the same values, lane 0 writes the pair's record
   const bool writer = threadIdx.x == 0;
   s.score = tot[0];
@@ -1035,18 +1084,23 @@ __device__ __forceinline__ void ndt_close_evaluation(NdtPair* st, const double* 
       }
   }
   CLOSE_STAMP(2)
-  ndt_advance(st, s, c, writer);
+  ndt_advance<false, QUEUE>(st, hdr_next ? hdr_next : st, s, c, writer);
   CLOSE_STAMP(3)
   // write the state back word by word across the wave (lane 0 alone would issue 38 stores one after the other)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS stores have landed
-  for (int w = threadIdx.x; w < kWords; w += kWave) reinterpret_cast<double*>(&st->s)[w] = reinterpret_cast<const double*>(&s_lds)[w];
+  for (int w = threadIdx.x; w < kWords; w += kWave) {
+    const double v = reinterpret_cast<const double*>(&s_lds)[w];
+    if (QUEUE) __hip_atomic_store(reinterpret_cast<double*>(&st->s) + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else reinterpret_cast<double*>(&st->s)[w] = v;
+  }
   if (writer && s.phase == PH_DONE) {
     st->active = 0;
     if (launch >= 0) st->last_launch = launch;
     atomicAdd(done_counter, 1);
   }
   CLOSE_STAMP(4)
+  return s.phase == PH_DONE;
 }
 
 __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
@@ -1098,7 +1152,7 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
 #pragma unroll
     for (int k = 0; k < 36; k++) s.hess[k] = tot[7 + k];  // upstream's full 6x6 (not exactly symmetric in float)
   }
-  ndt_advance<true>(st, s, c, writer);
+  ndt_advance<true>(st, st, s, c, writer);
   if (writer) {
     st->s = s;
     if (s.phase == PH_DONE) {
@@ -1108,13 +1162,157 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
   }
 }
 
+// ================================================================================================ the queue kernel
+// ONE persistent launch per align instead of one launch per evaluation.  A launch per evaluation pays, at every kernel boundary, the
+// whole serial tail of the slowest pair -- row hand-off, Newton step, More-Thuente state machine, trig of the next transform, the
+// dependent loads of the next prologue: t = 10.6 us + 1.49 us x (pairs still iterating) per launch on the 32-candidate bench step,
+// 38 launches, i.e. 0.4 ms of 1.44 ms spent with the chip waiting for 32 single waves (profiles/r03/tail_table_lockstep.json).  Here the pairs
+// advance independently: a work item is (pair, round, slice); the workgroup that closes round r of a pair opens its round r + 1, and
+// every other workgroup meanwhile works on the other pairs' slices -- the serial tail of one pair hides behind the derivative work of
+// the rest.  Workgroups are workers that CLAIM items (no worker ever waits for a particular other worker, so the kernel cannot
+// deadlock on workgroups that are not resident), pairs that finish stop offering items, the stragglers' rounds are cut into more
+// slices and get the whole chip, and a worker leaves when no pair is iterating any more.
+//   queue word of a pair (64 bits, own 64-byte line): [63:44] round | [43:32] slices of this round | [31:0] slices claimed.
+//   claim = one agent-scope atomic add of 1; the returned word tells round, slice count and the claimed slice at once.
+//   The slice count of a round is a fixed function of (batch shape, round number) -- never of timing -- so the partition of the
+//   sums, and with it every result bit, is reproducible run to run (ndt_queue_slices; the launch-per-evaluation path can be run with
+//   the same schedule for bit-for-bit comparison: DGS_NDT_QUEUE=0 DGS_NDT_SCHEDULE=1).
+//   Coherence inside the launch is per access, as for the rows (common.h): the closing workgroup writes the pair's record through
+//   (agent-scope stores), drains, and only then publishes the next round's queue word; workers read queue words, the record and the
+//   rows with agent-scope loads.  A worker whose poll guard runs out raises `abort` and everybody leaves (the align reports an error)
+//   instead of hanging the device.
+__host__ __device__ inline int ndt_queue_slices(int round, int base, int cap) {
+  const int f = round < 12 ? 1 : (round < 24 ? 2 : 4);
+  return min(base * f, cap);
+}
+constexpr int kQueueHdrWords = 82;                    // NdtPair: T[12], jang[8][3], hang[15][3], need_hessian
+static_assert(offsetof(NdtPair, need_hessian) == 81 * 4, "header layout");
+// What a round's derivative pass reads of the pair's record (transform, angle tables, need_hessian: the first 82 words of NdtPair) has
+// ONE SLOT PER ROUND, each in its own 128-byte lines: the closing workgroup of round r writes slot r + 1 through to memory before it
+// publishes round r + 1, and no cache of any XCD can hold an older copy of an address that nobody has read in this launch yet -- so the
+// workers read a slot with ordinary scalar loads, exactly like the launch-per-evaluation kernel reads the record after a kernel
+// boundary (keeping the 81 table entries in scalar registers read back through v_readlane cost 58 more instructions per point).
+constexpr size_t kQueueSlotBytes = 384;
+__host__ __device__ inline NdtPair* queue_slot(char* ring, int ring_rounds, int pair, int round) {
+  return reinterpret_cast<NdtPair*>(ring + ((size_t)pair * ring_rounds + round) * kQueueSlotBytes);
+}
+constexpr int kQueueCtlInts = 16;                     // [0] pairs still iterating, [1] abort
+constexpr unsigned long long kQueueClosed = 0xFFFFFull << 44;   // round = all ones, no slices: the pair has finished
+__device__ __forceinline__ unsigned long long* queue_word(int* queue, int pair) {
+  return reinterpret_cast<unsigned long long*>(queue + kQueueCtlInts) + 8 * (size_t)pair;
+}
+
+template <int SEARCH>
+__global__ __launch_bounds__(kBlock, 4) void ndt_queue_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes, NdtPair* pairs,
+                                                              const VoxelGrid g, const double gd1, const float gd2, const int leaf_pow2,
+                                                              double* partials, const int n_pairs, const int cap_blocks, const int slices_base,
+                                                              const NdtConsts consts, int* queue, int* __restrict__ done_counter, char* ring,
+                                                              const int ring_rounds) {
+  __shared__ unsigned long long s_item;
+  __shared__ int s_pair;
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63;
+  unsigned polls = 0;
+  for (;;) {
+    // ---- claim an item (wave 0; every lane holds the same values, lane 0 does the atomics)
+    if (threadIdx.x < kWave) {
+      int pair = -1;
+      unsigned long long item = 0;
+      for (;;) {
+        for (int c0 = 0; c0 < n_pairs && pair < 0; c0 += 64) {
+          const int pi = c0 + lane;
+          unsigned long long w = 0;
+          if (pi < n_pairs) w = __hip_atomic_load(queue_word(queue, pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned long long m = __ballot((unsigned)w < (unsigned)((w >> 32) & 0xFFFull));   // pairs with unclaimed slices
+          // start at a pair that depends on the worker, so that the workers spread over the pairs
+          const int rot = (int)((blockIdx.x * 11u + polls) & 63u);
+          m = (m >> rot) | (rot ? (m << (64 - rot)) : 0ull);
+          while (m != 0ull && pair < 0) {
+            const int bit = __ffsll((long long)m) - 1;
+            const int cand = c0 + ((bit + rot) & 63);
+            unsigned lo = 0, hi = 0;
+            if (lane == 0) {
+              const unsigned long long old = __hip_atomic_fetch_add(queue_word(queue, cand), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              lo = (unsigned)old; hi = (unsigned)(old >> 32);
+            }
+            lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+            if (lo < (hi & 0xFFFu)) { pair = cand; item = ((unsigned long long)hi << 32) | lo; }
+            m &= m - 1ull;
+          }
+        }
+        if (pair >= 0) break;
+        const int left = __hip_atomic_load(&queue[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int abort = __hip_atomic_load(&queue[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left <= 0 || abort != 0) break;
+        if (++polls > (1u << 22)) {   // ~10 s of polling without finding work: something is wrong -- leave, all of us
+          if (lane == 0) __hip_atomic_store(&queue[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(20);
+      }
+      if (lane == 0) { s_pair = pair; s_item = item; }
+    }
+    __syncthreads();
+    const int pair = s_pair;
+    if (pair < 0) return;
+    const unsigned long long item = s_item;
+    const int slice = (int)(unsigned)item, n_slices = (int)((item >> 32) & 0xFFFull), round = (int)(item >> 44);
+    // ---- the round's record slot: scalar loads (see kQueueSlotBytes)
+    const NdtPair& rec = *queue_slot(ring, ring_rounds, pair, round);
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = rec.T[k];
+    const int need_h_word = rec.need_hessian;
+    const bool need_h = need_h_word != 0;
+    const float4* __restrict__ src = src_ptrs[pair];
+    const int n = src_sizes[pair];
+    double acc[kAccum];
+#pragma unroll
+    for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
+    ndt_point_loop<SEARCH>(T, NdtHdrGlobal{rec}, need_h, src, n, slice * kBlock + (int)threadIdx.x, n_slices * kBlock, g, gd1, gd2, leaf_pow2, acc);
+    ndt_block_row<true>(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
+    // ---- publish the row, take a ticket; the workgroup that takes the round's last ticket closes it and opens the pair's next round
+    if (threadIdx.x < kAccumPad) handoff_drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, n_slices) ? 1 : 0;
+    __syncthreads();
+    if (s_last) {
+      // the next round's slot starts as a copy of this round's transform (an evaluation that only adds the Hessian at the accepted point
+      // keeps it); the optimiser then writes what changes.  Both through to memory, in this order.
+      NdtPair* next = queue_slot(ring, ring_rounds, pair, min(round + 1, ring_rounds - 1));
+      if (threadIdx.x < 12) {
+        __hip_atomic_store(&next->T[threadIdx.x], T[threadIdx.x < 12 ? threadIdx.x : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bool done = ndt_close_evaluation<true>(pairs + pair, partials + (size_t)pair * cap_blocks * kAccumPad, n_slices, consts, done_counter, 0x7FFFFFF0, next, need_h_word);
+      if (round + 2 >= ring_rounds) done = true;   // cannot happen: the optimiser ends a registration long before its slots run out
+      if (threadIdx.x < kWave) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the closing wave's write-through stores of the record have landed
+        if (threadIdx.x == 0) {
+          if (done) {
+            __hip_atomic_store(queue_word(queue, pair), kQueueClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&queue[0], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            const unsigned long long next = ((unsigned long long)(round + 1) << 44) | ((unsigned long long)ndt_queue_slices(round + 1, slices_base, cap_blocks) << 32);
+            __hip_atomic_store(queue_word(queue, pair), next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+    __syncthreads();   // LDS (item, record, reduction buffers) is re-used by the next item
+  }
+}
+
 // ================================================================================================ init / export
 __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __restrict__ inits, int n_pairs, const NdtConsts c, int probe,
                                 int* __restrict__ done_counter, const float4* const* __restrict__ stage_ptrs, const int* __restrict__ stage_sizes,
-                                const float4** __restrict__ src_ptrs, int* __restrict__ src_sizes) {
+                                const float4** __restrict__ src_ptrs, int* __restrict__ src_sizes, int* __restrict__ queue, const int queue_slices0,
+                                char* __restrict__ ring, const int ring_rounds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 16) done_counter[i] = 0;   // the first block has 64 threads: the counter block is cleared here, not by a fill command
+  if (queue && i < kQueueCtlInts) queue[i] = (i == 0) ? n_pairs : 0;   // queue kernel: pairs still iterating, abort flag
   if (i >= n_pairs) return;
+  if (queue) *queue_word(queue, i) = (unsigned long long)queue_slices0 << 32;   // round 0, nothing claimed
   src_ptrs[i] = stage_ptrs[i];
   src_sizes[i] = stage_sizes[i];
   NdtPair* st = pairs + i;
@@ -1134,7 +1332,7 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   for (int k = 0; k < 36; k++) s.hess[k] = 0;
   double x[6];
   for (int k = 0; k < 6; k++) x[k] = in.p0[k];
-  write_evaluation<false>(st, s, c, x, 1, false, true);
+  write_evaluation<false>(st, st, s, c, x, 1, false, true);
   // the first evaluation transforms the cloud by the GUESS matrix itself (computeTransformation)
   const float* G = in.guess;
   st->T[0] = G[0]; st->T[1] = G[4]; st->T[2] = G[8];  st->T[3] = G[12];
@@ -1145,6 +1343,11 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   st->active = 1;
   st->last_launch = 0x7FFFFFFF;
   st->ticket = 0;
+  if (queue) {   // queue kernel: the record slot of round 0
+    const int* from = reinterpret_cast<const int*>(st);
+    int* to = reinterpret_cast<int*>(queue_slot(ring, ring_rounds, i, 0));
+    for (int k = 0; k < kQueueHdrWords; k++) to[k] = from[k];
+  }
 }
 
 struct NdtOut {
@@ -1211,6 +1414,8 @@ struct NdtLaunch {
   int cap_blocks;    // most slices one pair can get (= rows reserved per pair in `partials`)
   int total_blocks;  // workgroups per derivative launch
   int max_n;         // largest source of the batch (row length of the ndt_strict_order 2 per-point table)
+  int queue_workers; // queue kernel: persistent workgroups; 0 = launch-per-evaluation path
+  int queue_base;    // queue kernel: slices of a pair's first rounds (ndt_queue_slices)
 };
 
 template <int SEARCH>
@@ -1299,17 +1504,38 @@ static NdtLaunch choose_launch(int n_pairs, int max_n) {
   L.cap_blocks = std::max(1, std::min((max_n + kBlock - 1) / kBlock, env_cap));             // at most 128 slices (partial rows) per pair
   L.total_blocks = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_blocks, env_total));  // ~4 workgroups per CU
   L.max_n = std::max(max_n, 1);
+  L.queue_workers = 0;
+  L.queue_base = 0;
   return L;
+}
+
+// Shape of the persistent queue kernel for this batch: workers (3 workgroups per CU by default: the fourth slot of every CU stays free
+// for the side stream's index build), and the slices of a pair's first rounds.
+static void choose_queue(dgs_handle* h, NdtLaunch& L) {
+  static const int env_workers = std::getenv("DGS_NDT_QUEUE_WORKERS") ? std::atoi(std::getenv("DGS_NDT_QUEUE_WORKERS")) : 768;
+  static const int env_base = std::getenv("DGS_NDT_QUEUE_BASE") ? std::atoi(std::getenv("DGS_NDT_QUEUE_BASE")) : 0;
+  const int64_t most = (int64_t)L.n_pairs * L.cap_blocks;
+  L.queue_workers = (int)std::max<int64_t>(1, std::min<int64_t>(env_workers, most));
+  L.queue_base = env_base > 0 ? std::min(env_base, L.cap_blocks) : std::max(1, std::min(L.cap_blocks, L.queue_workers / std::max(1, L.n_pairs)));
+  (void)h;
 }
 
 // Uploads pointers / sizes / initial poses, runs init, returns the launch shape.
 static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_host, const int* sizes_host, const float* guesses16,
-                     const double* probe_p6, NdtLaunch* launch_out) {
+                     const double* probe_p6, NdtLaunch* launch_out, bool use_queue = false) {
   hipStream_t st = h->stream;
   fill_consts(h);
   int max_n = 0;
   for (int i = 0; i < n_pairs; i++) max_n = std::max(max_n, sizes_host[i]);
-  const NdtLaunch L = choose_launch(n_pairs, max_n);
+  NdtLaunch L = choose_launch(n_pairs, max_n);
+  if (use_queue) {
+    choose_queue(h, L);
+    DGS_HIP_TRY(h, h->ndt_queue.reserve((size_t)kQueueCtlInts + 16 * (size_t)n_pairs));
+    // one record slot per pair and round; a registration ends within (max_iterations + 2) x (line-search trials + 2) evaluations
+    const int per_iter_q = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
+    h->ndt_ring_rounds = (h->prm.maximum_iterations + 3) * per_iter_q + 8;
+    DGS_HIP_TRY(h, h->ndt_ring.reserve((size_t)n_pairs * h->ndt_ring_rounds * kQueueSlotBytes));
+  }
   *launch_out = L;
   DGS_HIP_TRY(h, h->pairs.reserve(n_pairs));
   DGS_HIP_TRY(h, h->inits.reserve(n_pairs));
@@ -1351,16 +1577,57 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
   const char* dstage = reinterpret_cast<const char*>(h->inits.ptr);
   hipLaunchKernelGGL(ndt_init_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->pairs.ptr, h->inits.ptr, n_pairs, h->consts, probe_p6 ? 1 : 0,
                      h->done_counter.ptr, reinterpret_cast<const float4* const*>(dstage + (off_ptr - off_init)),
-                     reinterpret_cast<const int*>(dstage + (off_size - off_init)), h->src_ptrs.ptr, h->src_sizes.ptr);
+                     reinterpret_cast<const int*>(dstage + (off_size - off_init)), h->src_ptrs.ptr, h->src_sizes.ptr,
+                     L.queue_workers > 0 ? h->ndt_queue.ptr : nullptr, L.queue_workers > 0 ? ndt_queue_slices(0, L.queue_base, L.cap_blocks) : 0,
+                     reinterpret_cast<char*>(h->ndt_ring.ptr), h->ndt_ring_rounds);
   return DGS_OK;
 }
+
+static void launch_queue(dgs_handle* h, const NdtLaunch& L) {
+  const dim3 grid(L.queue_workers), block(kBlock);
+  const double gd1 = h->consts.gauss_d1;
+  const float gd2 = (float)h->consts.gauss_d2;
+  int fe = 0;
+  const int leaf_pow2 = (std::frexp(h->grid.leaf, &fe) == 0.5f) ? 1 : 0;
+  int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES);
+#define DGS_LAUNCH_QUEUE(SEARCH)                                                                                                                       \
+  hipLaunchKernelGGL((ndt_queue_kernel<SEARCH>), grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, gd1, gd2, leaf_pow2, \
+                     h->partials.ptr, L.n_pairs, L.cap_blocks, L.queue_base, h->consts, h->ndt_queue.ptr, h->done_counter.ptr,                \
+                     reinterpret_cast<char*>(h->ndt_ring.ptr), h->ndt_ring_rounds)
+  switch (h->consts.search_method) {
+    case DGS_NDT_DIRECT1: DGS_LAUNCH_QUEUE(DGS_NDT_DIRECT1); break;
+    case DGS_NDT_DIRECT26: DGS_LAUNCH_QUEUE(DGS_NDT_DIRECT26); break;
+    case DGS_NDT_KDTREE: DGS_LAUNCH_QUEUE(DGS_NDT_KDTREE); break;
+    default: DGS_LAUNCH_QUEUE(DGS_NDT_DIRECT7); break;
+  }
+#undef DGS_LAUNCH_QUEUE
+  prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
+}
+
+static int ndt_export(dgs_handle* h, int n_pairs, dgs_result* results);
 
 int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_host, const int* sizes_host, const float* guesses16,
                     dgs_result* results) {
   hipStream_t st = h->stream;
   NdtLaunch L{};
-  int rc = ndt_setup(h, n_pairs, src_ptrs_host, sizes_host, guesses16, nullptr, &L);
+  // the persistent queue kernel serves the default evaluation order (the validation orders keep their launch-per-evaluation kernels)
+  const bool use_queue = h->ndt_queue_mode != 0 && h->ndt_fused && (h->consts.strict_order == DGS_NDT_ORDER_FAST) && n_pairs >= h->ndt_queue_min_pairs;
+  int rc = ndt_setup(h, n_pairs, src_ptrs_host, sizes_host, guesses16, nullptr, &L, use_queue);
   if (rc != DGS_OK) return rc;
+  if (use_queue) {
+    launch_queue(h, L);
+    // the queue kernel leaves one workgroup slot per CU free: the side stream's index build (dgs_align_batch) runs beside it
+    if ((rc = side_build_now(h)) != DGS_OK) return rc;
+    int* hq = reinterpret_cast<int*>(h->pinned);
+    DGS_HIP_TRY(h, hipMemcpyAsync(hq, h->ndt_queue.ptr, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+    rc = ndt_export(h, n_pairs, results);
+    if (rc != DGS_OK) return rc;
+    if (hq[1] != 0 || hq[0] != 0) {
+      h->err = "ndt_queue_kernel gave up (poll guard): " + std::to_string(hq[0]) + " registrations unfinished";
+      return DGS_ERR_HIP;
+    }
+    return DGS_OK;
+  }
 
   // ---- iterate: chunks of (derivatives, solve) launches; the host looks at the done counter one chunk behind
   volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);  // [0], [1]: done counts of alternating chunks
@@ -1373,13 +1640,25 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   long queued = 0;
   const bool fused = h->ndt_fused && h->consts.strict_order == DGS_NDT_ORDER_FAST;
   int launch_no = 0;
+  // DGS_NDT_SCHEDULE=1 (tests): every launch cuts the pairs into the slices the queue kernel would give that round, so that the two
+  // paths sum the same partitions and can be compared bit for bit
+  const bool schedule = h->ndt_schedule;
+  NdtLaunch Lq = L;
+  if (schedule) choose_queue(h, Lq);
+  int round_no = 0;
   auto enqueue_chunk = [&](int slot, int launches) -> int {
     for (int e = 0; e < launches; e++) {
+      NdtLaunch Lr = L;
+      if (schedule) {
+        Lr.cap_blocks = ndt_queue_slices(round_no, Lq.queue_base, L.cap_blocks);
+        Lr.total_blocks = n_pairs * Lr.cap_blocks;
+      }
+      round_no++;
       if (fused) {
-        launch_derivatives(h, L, launch_no++);
+        launch_derivatives(h, Lr, launch_no++);
       } else {
-        launch_derivatives(h, L);
-        launch_solve(h, L);
+        launch_derivatives(h, Lr);
+        launch_solve(h, Lr);
       }
     }
     queued += launches;
@@ -1410,8 +1689,12 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   }
   if (rc != DGS_OK) return rc;
   (void)finished;  // pairs that did not finish inside max_evals export converged = 0
+  return ndt_export(h, n_pairs, results);
+}
 
-  // ---- export
+// ---- export: final transforms / flags / counts of every pair to the caller's result array
+static int ndt_export(dgs_handle* h, int n_pairs, dgs_result* results) {
+  hipStream_t st = h->stream;
   char* base = reinterpret_cast<char*>(h->pinned);
   const size_t off_out = ((256 + sizeof(NdtInit) * n_pairs + sizeof(void*) * n_pairs + sizeof(int) * n_pairs) + 255) & ~(size_t)255;
   NdtOut* hout = reinterpret_cast<NdtOut*>(base + off_out);
