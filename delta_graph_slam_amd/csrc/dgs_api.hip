@@ -299,6 +299,7 @@ void dgs_destroy(dgs_handle* h) {
   h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
   for (auto& ep : h->prof.pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->done_flags) (void)hipHostFree(h->done_flags);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

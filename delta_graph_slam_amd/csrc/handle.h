@@ -147,10 +147,12 @@ struct dgs_handle {
   dgs::DevBuf<dgs::NdtInit> inits;
   dgs::DevBuf<double> partials;       // [pair][block][kAccumPad]
   dgs::DevBuf<int> done_counter;      // [0] = finished pairs
+  int* done_flags = nullptr;          // pinned host memory, device-visible: one "finished" flag per pair of the running fused NDT batch
+  int done_flags_cap = 0;
   dgs::DevBuf<int> ndt_queue;         // queue kernel: 16 control ints, then one 64-byte line per pair (its queue word)
   dgs::DevBuf<unsigned char> ndt_ring;   // queue kernel: one 384-byte record slot per pair and round (ndt_align.hip, kQueueSlotBytes)
   int ndt_ring_rounds = 0;
-  int ndt_queue_mode = 1;             // DGS_NDT_QUEUE=0: one launch per evaluation (fused) instead of the persistent queue kernel
+  int ndt_queue_mode = 0;             // DGS_NDT_QUEUE=1 (experiments build): the persistent queue kernel instead of one launch per evaluation (measured slower)
   bool ndt_schedule = false;          // DGS_NDT_SCHEDULE=1 (tests): the launch-per-evaluation path cuts every round like the queue kernel would
   int ndt_queue_min_pairs = 2;        // DGS_NDT_QUEUE_MIN_PAIRS: batches smaller than this keep the launch-per-evaluation path
   dgs::DevBuf<int> pair_blocks;       // slices the last derivative launch gave each pair

@@ -11,8 +11,8 @@
 //     coalesced 16-B loads of XYZ1 points, 7 (1/27) dependent 4-B cell lookups, 48-B voxel records from L2,
 //     float per-point math, double accumulation, wave shuffle -> LDS -> one 28-double partial row per block.
 //     No atomics: the rows are summed in a fixed order by ndt_solve, so results are bit-reproducible.
-//   * Per point the 7 voxels are folded first into A = sum w C, b = sum w C q, M = sum w d2 (Cq)(Cq)^T and then
-//     projected once through the point Jacobian:  g = J^T b,  H = J^T (A - M) J + b . d2T/dp2  -- algebraically
+//   * Per point the 7 voxels are folded first into b = sum w C q and N = sum w C - sum w d2 (Cq)(Cq)^T and then
+//     projected once through the point Jacobian:  g = J^T b,  H = J^T N J + b . d2T/dp2  -- algebraically
 //     the upstream per-voxel update (eq. 6.12/6.13) at ~1/3 of the flops.
 //   * ndt_solve (one workgroup per pair) finishes the reduction and runs Newton + the More-Thuente state
 //     machine on lane 0, then writes the next evaluation's float transform and angle tables in place, so an
@@ -64,7 +64,7 @@ __device__ __forceinline__ void neighbour_offset(int k, int& dx, int& dy, int& d
   }
 }
 
-template <bool QUEUE = false>
+template <bool QUEUE = false, bool DONE_FLAG = false>
 __device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch,
                                                      NdtPair* hdr_next = nullptr, int need_h_in = -1);
 
@@ -135,7 +135,7 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
     }
 
     // ---- fold the neighbourhood:  A = sum w C,  b = sum w C q,  M = sum w d2 (Cq)(Cq)^T,  score
-    float A[6] = {0, 0, 0, 0, 0, 0}, M[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, sc = 0.f;
+    float N[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, sc = 0.f;   // N = A - M, accumulated directly
     bool any = false;
 #pragma unroll
     for (int k = 0; k < NB; k++) {
@@ -147,9 +147,9 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
       }
       const VoxelRec* __restrict__ rec = g.vox + vid[k];
       const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);  // three aligned 16-B loads
-      const float4 ra = r4[0], rb = r4[1], rc = r4[2];
-      const double mx = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x));
-      const double my = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z));
+      const double2 m01 = *reinterpret_cast<const double2*>(rec);
+      const float4 rb = r4[1], rc = r4[2];
+      const double mx = m01.x, my = m01.y;
       const double mz = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
       const float q0 = (float)((double)xt0 - mx), q1 = (float)((double)xt1 - my), q2 = (float)((double)xt2 - mz);
       const float Cxx = rb.z, Cxy = rb.w, Cxz = rc.x, Cyy = rc.y, Cyz = rc.z, Czz = rc.w;
@@ -163,19 +163,28 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
       e = gd2 * e;
       if (e > 1.f || e < 0.f || e != e) continue;  // upstream "error checking for invalid values"
       const float w = (float)((double)e * gd1);
-      const float wd = w * gd2;
       sc += score_inc;
       any = true;
       b[0] += w * u0; b[1] += w * u1; b[2] += w * u2;
-      A[0] += w * Cxx; A[1] += w * Cxy; A[2] += w * Cxz; A[3] += w * Cyy; A[4] += w * Cyz; A[5] += w * Czz;
-      M[0] += wd * u0 * u0; M[1] += wd * u0 * u1; M[2] += wd * u0 * u2; M[3] += wd * u1 * u1; M[4] += wd * u1 * u2; M[5] += wd * u2 * u2;
+      if (need_h) {   // a score + gradient evaluation (a More-Thuente trial) needs neither A nor M: wave-uniform, a scalar branch
+        const float wd = w * gd2, t0 = wd * u0, t1 = wd * u1, t2 = wd * u2;
+        N[0] += w * Cxx; N[1] += w * Cxy; N[2] += w * Cxz; N[3] += w * Cyy; N[4] += w * Cyz; N[5] += w * Czz;
+        N[0] -= t0 * u0; N[1] -= t0 * u1; N[2] -= t0 * u2; N[3] -= t1 * u1; N[4] -= t1 * u2; N[5] -= t2 * u2;
+      }
     }
     if (!any) continue;
 
     // ---- project through the point Jacobian (eq. 6.18/6.19): J = [I | J3 J4 J5]
+    // Rows 5..7 of the table have no z entry (computeAngleDerivatives writes exact zeros there), and the xy parts of rows 0 / 1 are kept:
+    // the second-derivative rows f3 / f2 are exactly those (below).
     float xj[8];
+    const float jxy0 = hdr.J(0, 0) * x.x + hdr.J(0, 1) * x.y, jxy1 = hdr.J(1, 0) * x.x + hdr.J(1, 1) * x.y;
+    xj[0] = jxy0 + hdr.J(0, 2) * x.z;
+    xj[1] = jxy1 + hdr.J(1, 2) * x.z;
 #pragma unroll
-    for (int k = 0; k < 8; k++) xj[k] = hdr.J(k, 0) * x.x + hdr.J(k, 1) * x.y + hdr.J(k, 2) * x.z;
+    for (int k = 2; k < 5; k++) xj[k] = hdr.J(k, 0) * x.x + hdr.J(k, 1) * x.y + hdr.J(k, 2) * x.z;
+#pragma unroll
+    for (int k = 5; k < 8; k++) xj[k] = hdr.J(k, 0) * x.x + hdr.J(k, 1) * x.y;
     const float J3[3] = {0.f, xj[0], xj[1]}, J4[3] = {xj[2], xj[3], xj[4]}, J5[3] = {xj[5], xj[6], xj[7]};
     acc[0] += (double)sc;
     acc[1] += (double)b[0];
@@ -185,14 +194,24 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
     acc[5] += (double)(b[0] * J4[0] + b[1] * J4[1] + b[2] * J4[2]);
     acc[6] += (double)(b[0] * J5[0] + b[1] * J5[1] + b[2] * J5[2]);
     if (need_h) {
-      const float N0 = A[0] - M[0], N1 = A[1] - M[1], N2 = A[2] - M[2], N3 = A[3] - M[3], N4 = A[4] - M[4], N5 = A[5] - M[5];
+      const float N0 = N[0], N1 = N[1], N2 = N[2], N3 = N[3], N4 = N[4], N5 = N[5];
       // N * J_k
       const float n3[3] = {N1 * J3[1] + N2 * J3[2], N3 * J3[1] + N4 * J3[2], N4 * J3[1] + N5 * J3[2]};
       const float n4[3] = {N0 * J4[0] + N1 * J4[1] + N2 * J4[2], N1 * J4[0] + N3 * J4[1] + N4 * J4[2], N2 * J4[0] + N4 * J4[1] + N5 * J4[2]};
       const float n5[3] = {N0 * J5[0] + N1 * J5[1] + N2 * J5[2], N1 * J5[0] + N3 * J5[1] + N4 * J5[2], N2 * J5[0] + N4 * J5[1] + N5 * J5[2]};
+      // Of the fifteen second-derivative rows (eq. 6.21) nine are first-derivative rows (eq. 6.19) again, as computeAngleDerivatives
+      // writes them -- the same double expressions or their exact negations, so the float entries are the same bits:
+      //   a2 = -j1, a3 = j0, b2 = -j4, b3 = j3, c2 = -j7, c3 = j6;  f1 = xy part of d1, f2 = xy part of a2, f3 = xy part of a3;
+      // e1..e3 (and c2, c3, f1..f3) have no z entry.  Same values as the full 15 x 3 products, 30 instructions fewer per point.
       float xh[15];
+      xh[0] = -xj[1]; xh[1] = xj[0]; xh[2] = -xj[4]; xh[3] = xj[3]; xh[4] = -xj[7]; xh[5] = xj[6];
+      const float hxy6 = hdr.H(6, 0) * x.x + hdr.H(6, 1) * x.y;
+      xh[6] = hxy6 + hdr.H(6, 2) * x.z;
 #pragma unroll
-      for (int k = 0; k < 15; k++) xh[k] = hdr.H(k, 0) * x.x + hdr.H(k, 1) * x.y + hdr.H(k, 2) * x.z;
+      for (int k = 7; k < 9; k++) xh[k] = hdr.H(k, 0) * x.x + hdr.H(k, 1) * x.y + hdr.H(k, 2) * x.z;
+#pragma unroll
+      for (int k = 9; k < 12; k++) xh[k] = hdr.H(k, 0) * x.x + hdr.H(k, 1) * x.y;
+      xh[12] = hxy6; xh[13] = -jxy1; xh[14] = jxy0;
       // b . second derivatives: a=(0,xh0,xh1) b=(0,xh2,xh3) c=(0,xh4,xh5) d=(xh6..8) e=(xh9..11) f=(xh12..14)
       const float ba = b[1] * xh[0] + b[2] * xh[1];
       const float bb = b[1] * xh[2] + b[2] * xh[3];
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
 #ifdef DGS_CLOSE_STAMPS
   if (threadIdx.x == 0 && pairs[pair].s.nr_iterations == 1) pairs[pair].traj[kTrajCap - 1][5] = (double)wall_clock64();
 #endif
-  ndt_close_evaluation(pairs + pair, partials + (size_t)pair * cap_blocks * kAccumPad, blocks_per_pair, consts, done_counter, launch);
+  ndt_close_evaluation<false, true>(pairs + pair, partials + (size_t)pair * cap_blocks * kAccumPad, blocks_per_pair, consts, done_counter + pair, launch);
 }
 
 // Everything below this line -- the validation-mode evaluation, the optimiser (Newton step, More-Thuente state machine,
@@ -1021,7 +1040,10 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
 // QUEUE: called inside the persistent queue kernel -- the pair's record was written by another workgroup of the SAME launch and will be
 // read by others: coherent (agent-scope) loads and write-through stores for every word of it.  Returns (to the closing wave) whether
 // the registration has ended.
-template <bool QUEUE>
+// DONE_FLAG: `done_counter` is this pair's own flag in HOST memory (pinned, device-visible): a finished pair stores 1 into it and the host
+// counts the flags at every chunk boundary -- no copy command between the chunks of launches (each cost the stream ~8 us: a blit kernel
+// and two barriers).  Otherwise a device counter that the host copies back.
+template <bool QUEUE, bool DONE_FLAG>
 __device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* partials_of_pair, int blocks_per_pair, const NdtConsts& c, int* done_counter, int launch,
                                                      NdtPair* hdr_next, int need_h_in) {
   CLOSE_STAMP(0)
@@ -1097,7 +1119,8 @@ __device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* 
   if (writer && s.phase == PH_DONE) {
     st->active = 0;
     if (launch >= 0) st->last_launch = launch;
-    atomicAdd(done_counter, 1);
+    if (DONE_FLAG) __hip_atomic_store(done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else atomicAdd(done_counter, 1);
   }
   CLOSE_STAMP(4)
   return s.phase == PH_DONE;
@@ -1163,6 +1186,9 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
 }
 
 // ================================================================================================ the queue kernel
+// STATUS (round 3): correct -- bit for bit equal to the launch-per-evaluation path under the same slice schedule
+// (tests/test_queue_gpu.py) -- and SLOWER: 3.9-4.9 ms per 32-candidate step against 1.5 ms (DESIGN.md has the phase breakdown).  Off by
+// default and compiled into the experiments build only.
 // ONE persistent launch per align instead of one launch per evaluation.  A launch per evaluation pays, at every kernel boundary, the
 // whole serial tail of the slowest pair -- row hand-off, Newton step, More-Thuente state machine, trig of the next transform, the
 // dependent loads of the next prologue: t = 10.6 us + 1.49 us x (pairs still iterating) per launch on the 32-candidate bench step,
@@ -1196,12 +1222,16 @@ constexpr size_t kQueueSlotBytes = 384;
 __host__ __device__ inline NdtPair* queue_slot(char* ring, int ring_rounds, int pair, int round) {
   return reinterpret_cast<NdtPair*>(ring + ((size_t)pair * ring_rounds + round) * kQueueSlotBytes);
 }
-constexpr int kQueueCtlInts = 16;                     // [0] pairs still iterating, [1] abort
-constexpr unsigned long long kQueueClosed = 0xFFFFFull << 44;   // round = all ones, no slices: the pair has finished
-__device__ __forceinline__ unsigned long long* queue_word(int* queue, int pair) {
-  return reinterpret_cast<unsigned long long*>(queue + kQueueCtlInts) + 8 * (size_t)pair;
-}
+// Queue memory: 64-bit words, contiguous -- word 0 = control ([31:0] pairs still iterating, bit 32 abort), word 1 + p = pair p.  A worker
+// looking for work reads control and up to 63 pairs with ONE wave-wide load of four 128-byte lines (one line per pair made every
+// idle poll 34 line requests to the same memory channel: measured 110 polls per us by 768 workers, items three times slower).
+__device__ __forceinline__ unsigned long long* queue_word(int* queue, int pair) { return reinterpret_cast<unsigned long long*>(queue) + 1 + pair; }
+__device__ __forceinline__ unsigned long long* queue_ctl(int* queue) { return reinterpret_cast<unsigned long long*>(queue); }
+constexpr int kQueueStatInts = 16;   // diagnostic build: counters behind the words
 
+#ifdef DGS_EXPERIMENTS   // measured slower than one launch per evaluation (see the status note above): experiments build only
+constexpr unsigned long long kQueueClosed = 0xFFFFFull << 44;   // round = all ones, no slices: the pair has finished
+constexpr unsigned long long kQueueAbort = 1ull << 32;
 template <int SEARCH>
 __global__ __launch_bounds__(kBlock, 4) void ndt_queue_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes, NdtPair* pairs,
                                                               const VoxelGrid g, const double gd1, const float gd2, const int leaf_pow2,
@@ -1213,48 +1243,87 @@ __global__ __launch_bounds__(kBlock, 4) void ndt_queue_kernel(const float4* cons
   __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   unsigned polls = 0;
+#ifdef DGS_QUEUE_STATS
+  unsigned acc_polls = 0, acc_failed = 0, acc_claims = 0, acc_closings = 0;
+  unsigned long long acc_look = 0, acc_item = 0, acc_rec = 0, acc_loop = 0, acc_row = 0, acc_ticket = 0, acc_close = 0;
+#define QSTAMP(var) const unsigned long long var = wall_clock64();
+#else
+#define QSTAMP(var)
+#endif
   for (;;) {
     // ---- claim an item (wave 0; every lane holds the same values, lane 0 does the atomics)
     if (threadIdx.x < kWave) {
       int pair = -1;
       unsigned long long item = 0;
+#ifdef DGS_QUEUE_STATS
+      const unsigned long long t_claim0 = wall_clock64();
+      unsigned st_polls = 0, st_failed = 0;
+#endif
+      unsigned idle = 0;
       for (;;) {
-        for (int c0 = 0; c0 < n_pairs && pair < 0; c0 += 64) {
-          const int pi = c0 + lane;
+#ifdef DGS_QUEUE_STATS
+        st_polls++;
+#endif
+        int left = 0, abort = 0;
+        for (int c0 = 0; c0 <= n_pairs && pair < 0; c0 += 64) {
+          const int idx = c0 + lane;   // queue word index: 0 = control, 1 + p = pair p
           unsigned long long w = 0;
-          if (pi < n_pairs) w = __hip_atomic_load(queue_word(queue, pi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          unsigned long long m = __ballot((unsigned)w < (unsigned)((w >> 32) & 0xFFFull));   // pairs with unclaimed slices
-          // start at a pair that depends on the worker, so that the workers spread over the pairs
-          const int rot = (int)((blockIdx.x * 11u + polls) & 63u);
-          m = (m >> rot) | (rot ? (m << (64 - rot)) : 0ull);
-          while (m != 0ull && pair < 0) {
-            const int bit = __ffsll((long long)m) - 1;
-            const int cand = c0 + ((bit + rot) & 63);
-            unsigned lo = 0, hi = 0;
-            if (lane == 0) {
-              const unsigned long long old = __hip_atomic_fetch_add(queue_word(queue, cand), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              lo = (unsigned)old; hi = (unsigned)(old >> 32);
-            }
-            lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
-            if (lo < (hi & 0xFFFu)) { pair = cand; item = ((unsigned long long)hi << 32) | lo; }
-            m &= m - 1ull;
+          if (idx <= n_pairs) w = __hip_atomic_load(queue_ctl(queue) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (c0 == 0) {
+            left = __builtin_amdgcn_readfirstlane((int)(unsigned)w);
+            abort = __builtin_amdgcn_readfirstlane((int)(unsigned)(w >> 32)) & 1;
           }
+          unsigned long long m = __ballot(idx >= 1 && idx <= n_pairs && (unsigned)w < (unsigned)((w >> 32) & 0xFFFull));   // pairs with unclaimed slices
+          if (m == 0ull) continue;
+          // ONE attempt per look, at a pair that depends on the worker (so that the workers spread over the pairs); a worker that loses
+          // the race looks again instead of walking down a stale list (which is what turns a few late workers into a herd)
+          const int rot = (int)((blockIdx.x * 11u + polls + idle) & 63u);
+          m = (m >> rot) | (rot ? (m << (64 - rot)) : 0ull);
+          const int cand = c0 + ((__ffsll((long long)m) - 1 + rot) & 63) - 1;
+          unsigned lo = 0, hi = 0;
+          if (lane == 0) {
+            const unsigned long long old = __hip_atomic_fetch_add(queue_word(queue, cand), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lo = (unsigned)old; hi = (unsigned)(old >> 32);
+          }
+          lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi);
+          if (lo < (hi & 0xFFFu)) { pair = cand; item = ((unsigned long long)hi << 32) | lo; }
+#ifdef DGS_QUEUE_STATS
+          else st_failed++;
+#endif
+          c0 = n_pairs + 1;   // leave the scan: claimed, or look again
+          idle = 0;
         }
         if (pair >= 0) break;
-        const int left = __hip_atomic_load(&queue[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int abort = __hip_atomic_load(&queue[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left <= 0 || abort != 0) break;
-        if (++polls > (1u << 22)) {   // ~10 s of polling without finding work: something is wrong -- leave, all of us
-          if (lane == 0) __hip_atomic_store(&queue[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a worker that can never be needed again leaves: at most cap_blocks slices per pair still iterating can ever be on offer
+        if ((long long)blockIdx.x >= (long long)left * cap_blocks) break;
+        if (++polls > (1u << 22)) {   // seconds of polling without finding work: something is wrong -- leave, all of us
+          if (lane == 0) __hip_atomic_fetch_or(queue_ctl(queue), kQueueAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
         }
-        __builtin_amdgcn_s_sleep(20);
+        // back off: the longer nothing was on offer, the longer the nap (0.5 us ... 8 us); whoever just lost a race looks again at once
+        idle = min(idle + 1u, 5u);
+        for (unsigned k = 0; k < (1u << (idle - 1u)); k++) __builtin_amdgcn_s_sleep(16);
       }
       if (lane == 0) { s_pair = pair; s_item = item; }
+#ifdef DGS_QUEUE_STATS
+      acc_polls += st_polls; acc_failed += st_failed; acc_claims += pair >= 0 ? 1 : 0; acc_look += wall_clock64() - t_claim0;
+#endif
     }
     __syncthreads();
     const int pair = s_pair;
-    if (pair < 0) return;
+    if (pair < 0) {
+#ifdef DGS_QUEUE_STATS
+      if (threadIdx.x == 0) {   // diagnostic build: this worker's counters (100 MHz ticks), flushed once
+        int* stat = queue + 2 * (n_pairs + 2);
+        atomicAdd(&stat[2], (int)acc_polls); atomicAdd(&stat[3], (int)acc_failed); atomicAdd(&stat[4], (int)acc_claims); atomicAdd(&stat[7], (int)acc_closings);
+        atomicAdd(&stat[5], (int)acc_look); atomicAdd(&stat[6], (int)acc_item);
+        atomicAdd(&stat[8], (int)acc_rec); atomicAdd(&stat[9], (int)acc_loop); atomicAdd(&stat[10], (int)acc_row); atomicAdd(&stat[11], (int)acc_ticket); atomicAdd(&stat[12], (int)acc_close);
+      }
+#endif
+      return;
+    }
+    QSTAMP(t_item0)
     const unsigned long long item = s_item;
     const int slice = (int)(unsigned)item, n_slices = (int)((item >> 32) & 0xFFFull), round = (int)(item >> 44);
     // ---- the round's record slot: scalar loads (see kQueueSlotBytes)
@@ -1269,16 +1338,27 @@ __global__ __launch_bounds__(kBlock, 4) void ndt_queue_kernel(const float4* cons
     double acc[kAccum];
 #pragma unroll
     for (int k = 0; k < kAccum; k++) acc[k] = 0.0;
+#ifdef DGS_QUEUE_STATS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    QSTAMP(t_rec)
     ndt_point_loop<SEARCH>(T, NdtHdrGlobal{rec}, need_h, src, n, slice * kBlock + (int)threadIdx.x, n_slices * kBlock, g, gd1, gd2, leaf_pow2, acc);
+    QSTAMP(t_loop)
     ndt_block_row<true>(acc, partials + ((size_t)pair * cap_blocks + slice) * kAccumPad);
     // ---- publish the row, take a ticket; the workgroup that takes the round's last ticket closes it and opens the pair's next round
     if (threadIdx.x < kAccumPad) handoff_drain_stores();
     __syncthreads();
+    QSTAMP(t_row)
     if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, n_slices) ? 1 : 0;
     __syncthreads();
+    QSTAMP(t_ticket)
     if (s_last) {
       // the next round's slot starts as a copy of this round's transform (an evaluation that only adds the Hessian at the accepted point
       // keeps it); the optimiser then writes what changes.  Both through to memory, in this order.
+      // The closing wave is ONE wave on a SIMD that it shares with the derivative loops of other workers: at equal priority its serial
+      // chain (row sums, Newton step, line-search state machine, trig) runs at a third of its speed (measured 33 us against 8 us at the end
+      // of a lockstep launch, where the SIMD is idle) -- and the pair's next round cannot open before it is through.  Raise it.
+      __builtin_amdgcn_s_setprio(3);
       NdtPair* next = queue_slot(ring, ring_rounds, pair, min(round + 1, ring_rounds - 1));
       if (threadIdx.x < 12) {
         __hip_atomic_store(&next->T[threadIdx.x], T[threadIdx.x < 12 ? threadIdx.x : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1291,17 +1371,26 @@ __global__ __launch_bounds__(kBlock, 4) void ndt_queue_kernel(const float4* cons
         if (threadIdx.x == 0) {
           if (done) {
             __hip_atomic_store(queue_word(queue, pair), kQueueClosed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&queue[0], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(queue_ctl(queue), ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one pair fewer (the count is > 0: no borrow into the abort bit)
           } else {
             const unsigned long long next = ((unsigned long long)(round + 1) << 44) | ((unsigned long long)ndt_queue_slices(round + 1, slices_base, cap_blocks) << 32);
             __hip_atomic_store(queue_word(queue, pair), next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
     }
+#ifdef DGS_QUEUE_STATS
+    {
+      const unsigned long long t_end = wall_clock64();
+      acc_item += t_end - t_item0; acc_rec += t_rec - t_item0; acc_loop += t_loop - t_rec; acc_row += t_row - t_loop; acc_ticket += t_ticket - t_row;
+      if (s_last) { acc_close += t_end - t_ticket; acc_closings++; }
+    }
+#endif
     __syncthreads();   // LDS (item, record, reduction buffers) is re-used by the next item
   }
 }
+#endif  // DGS_EXPERIMENTS
 
 // ================================================================================================ init / export
 __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __restrict__ inits, int n_pairs, const NdtConsts c, int probe,
@@ -1310,7 +1399,8 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
                                 char* __restrict__ ring, const int ring_rounds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 16) done_counter[i] = 0;   // the first block has 64 threads: the counter block is cleared here, not by a fill command
-  if (queue && i < kQueueCtlInts) queue[i] = (i == 0) ? n_pairs : 0;   // queue kernel: pairs still iterating, abort flag
+  if (queue && i == 0) *queue_ctl(queue) = (unsigned long long)n_pairs;   // queue kernel: pairs still iterating, abort bit clear
+  if (queue && i < kQueueStatInts) queue[2 * (n_pairs + 2) + i] = 0;
   if (i >= n_pairs) return;
   if (queue) *queue_word(queue, i) = (unsigned long long)queue_slices0 << 32;   // round 0, nothing claimed
   src_ptrs[i] = stage_ptrs[i];
@@ -1458,7 +1548,7 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
   }
 #define DGS_LAUNCH_DERIV(SEARCH, FUSED, PACK)                                                                                                            \
   hipLaunchKernelGGL((ndt_derivatives_kernel<SEARCH, FUSED, PACK>), grid, block, 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, gd1, gd2, \
-                     leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts, h->done_counter.ptr, launch)
+                     leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts, (launch >= 0 ? h->done_flags : h->done_counter.ptr), launch)
   if (launch >= 0) {
     switch (h->consts.search_method) {
       case DGS_NDT_DIRECT1: DGS_LAUNCH_DERIV(DGS_NDT_DIRECT1, true, false); break;
@@ -1530,7 +1620,7 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
   NdtLaunch L = choose_launch(n_pairs, max_n);
   if (use_queue) {
     choose_queue(h, L);
-    DGS_HIP_TRY(h, h->ndt_queue.reserve((size_t)kQueueCtlInts + 16 * (size_t)n_pairs));
+    DGS_HIP_TRY(h, h->ndt_queue.reserve(2 * ((size_t)n_pairs + 2) + kQueueStatInts));
     // one record slot per pair and round; a registration ends within (max_iterations + 2) x (line-search trials + 2) evaluations
     const int per_iter_q = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
     h->ndt_ring_rounds = (h->prm.maximum_iterations + 3) * per_iter_q + 8;
@@ -1583,6 +1673,7 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
   return DGS_OK;
 }
 
+#ifdef DGS_EXPERIMENTS
 static void launch_queue(dgs_handle* h, const NdtLaunch& L) {
   const dim3 grid(L.queue_workers), block(kBlock);
   const double gd1 = h->consts.gauss_d1;
@@ -1603,6 +1694,9 @@ static void launch_queue(dgs_handle* h, const NdtLaunch& L) {
 #undef DGS_LAUNCH_QUEUE
   prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
 }
+#else
+static void launch_queue(dgs_handle*, const NdtLaunch&) {}
+#endif
 
 static int ndt_export(dgs_handle* h, int n_pairs, dgs_result* results);
 
@@ -1611,17 +1705,30 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   hipStream_t st = h->stream;
   NdtLaunch L{};
   // the persistent queue kernel serves the default evaluation order (the validation orders keep their launch-per-evaluation kernels)
-  const bool use_queue = h->ndt_queue_mode != 0 && h->ndt_fused && (h->consts.strict_order == DGS_NDT_ORDER_FAST) && n_pairs >= h->ndt_queue_min_pairs;
+  const bool use_queue = kExperiments && h->ndt_queue_mode != 0 && h->ndt_fused && (h->consts.strict_order == DGS_NDT_ORDER_FAST) && n_pairs >= h->ndt_queue_min_pairs;
   int rc = ndt_setup(h, n_pairs, src_ptrs_host, sizes_host, guesses16, nullptr, &L, use_queue);
   if (rc != DGS_OK) return rc;
   if (use_queue) {
     launch_queue(h, L);
     // the queue kernel leaves one workgroup slot per CU free: the side stream's index build (dgs_align_batch) runs beside it
     if ((rc = side_build_now(h)) != DGS_OK) return rc;
-    int* hq = reinterpret_cast<int*>(h->pinned);
+    int* hq = reinterpret_cast<int*>(h->pinned);   // control word: [0] pairs unfinished, [1] abort bit
     DGS_HIP_TRY(h, hipMemcpyAsync(hq, h->ndt_queue.ptr, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
     rc = ndt_export(h, n_pairs, results);
     if (rc != DGS_OK) return rc;
+#ifdef DGS_QUEUE_STATS
+    {
+      int q[8];
+      (void)hipMemcpy(q, h->ndt_queue.ptr + 2 * (n_pairs + 2), sizeof(q), hipMemcpyDeviceToHost);
+      int q2[8];
+      (void)hipMemcpy(q2, h->ndt_queue.ptr + 2 * (n_pairs + 2) + 8, sizeof(q2), hipMemcpyDeviceToHost);
+      const double it = std::max(1, q[4]);
+      std::fprintf(stderr, "[queue] workers %d base %d: polls %d failed_claims %d claims %d closings %d; per worker: looking for work %.1f us, in items %.1f us; per item: %.2f us = record %.2f + "
+                   "points %.2f + row %.2f + ticket %.2f; per closing %.2f us\n",
+                   L.queue_workers, L.queue_base, q[2], q[3], q[4], q[7], q[5] * 0.01 / L.queue_workers, q[6] * 0.01 / L.queue_workers, q[6] * 0.01 / it, q2[0] * 0.01 / it,
+                   q2[1] * 0.01 / it, q2[2] * 0.01 / it, q2[3] * 0.01 / it, q2[4] * 0.01 / std::max(1, q[7]));
+    }
+#endif
     if (hq[1] != 0 || hq[0] != 0) {
       h->err = "ndt_queue_kernel gave up (poll guard): " + std::to_string(hq[0]) + " registrations unfinished";
       return DGS_ERR_HIP;
@@ -1633,6 +1740,17 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);  // [0], [1]: done counts of alternating chunks
   flags[0] = flags[1] = 0;
   if (ensure_poll_events(h) != DGS_OK) return DGS_ERR_HIP;
+  const bool fused_flags = h->ndt_fused && h->consts.strict_order == DGS_NDT_ORDER_FAST;
+  if (fused_flags) {   // fused launches: every pair has a "finished" flag in pinned host memory that its closing workgroup sets
+    if (h->done_flags_cap < n_pairs) {
+      if (h->done_flags) (void)hipHostFree(h->done_flags);
+      h->done_flags = nullptr;
+      h->done_flags_cap = 0;
+      DGS_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->done_flags), sizeof(int) * (size_t)(n_pairs + 64), hipHostMallocDefault));
+      h->done_flags_cap = n_pairs + 64;
+    }
+    for (int i = 0; i < n_pairs; i++) h->done_flags[i] = 0;   // nothing of this handle is in flight: the previous align has been synchronised
+  }
   hipEvent_t* ev = h->ev_poll;
   const int per_iter = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
   const long max_evals = (long)(h->prm.maximum_iterations + 3) * per_iter + 2;
@@ -1662,9 +1780,15 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
       }
     }
     queued += launches;
-    DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!fused_flags) DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
     DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
     return DGS_OK;
+  };
+  auto pairs_done = [&](int slot) -> int {
+    if (!fused_flags) return flags[slot];
+    int n = 0;
+    for (int i = 0; i < n_pairs; i++) n += reinterpret_cast<volatile int*>(h->done_flags)[i];
+    return n;
   };
   int cur = 0;
   // with a build waiting for the side stream the first chunk is twice as long: the host needs ~0.1 ms to enqueue that build, and
@@ -1683,7 +1807,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
     first = false;
     hipError_t e = hipEventSynchronize(ev[cur]);
     if (e != hipSuccess) { h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; break; }
-    if (flags[cur] >= n_pairs) { finished = true; break; }
+    if (pairs_done(cur) >= n_pairs) { finished = true; break; }
     if (!more) break;
     cur ^= 1;
   }

@@ -145,10 +145,12 @@ class LoopDetector:
         gathered [n_candidates, RECORD_WIDTH] float64 records in original candidate order."""
         rank, world = self._world()
         n = len(candidates)
-        self.registration.setInputTarget(self.resident(new_keyframe, as_target=True))
+        # the host-side preparation of the candidate loop first: setInputTarget leaves the device building the target's voxel model, and
+        # nothing should stand between that and the batch's first launch
         mine = list(range(rank, n, world))
         sources = [self.resident(candidates[c]) for c in mine]
         guesses = self.guesses_for(new_keyframe, [candidates[c] for c in mine])
+        self.registration.setInputTarget(self.resident(new_keyframe, as_target=True))
         per_rank = (n + world - 1) // world
         rec = np.full((per_rank, RECORD_WIDTH), -1.0, dtype=np.float64)
         if mine:

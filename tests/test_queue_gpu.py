@@ -2,7 +2,8 @@
 pairs advance independently -- against the launch-per-evaluation path.  The slice count of a round is a fixed function of the batch
 shape and the round number, so the launch-per-evaluation path can be made to cut every round the same way (DGS_NDT_SCHEDULE=1) and
 the two must then agree BIT FOR BIT: same transforms, scores, iteration / evaluation counts, trajectories and fitness scores.  That
-pins the queue kernel's hand-offs (queue words, per-round record slots, rows, tickets) on every search method and batch shape."""
+pins the queue kernel's hand-offs (queue words, per-round record slots, rows, tickets) on every search method and batch shape.
+The queue kernel is an EXPERIMENT (measured slower): it is compiled into libdgs_reg_exp.so only and off by default."""
 import os
 
 import numpy as np
@@ -19,7 +20,7 @@ def _reg(env, **kw):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        return Registration("NDT_OMP", **kw)
+        return Registration("NDT_OMP", lib_path=L.EXPERIMENTS_LIB_PATH, **kw)   # the queue kernel lives in the experiments build
     finally:
         for k, v in old.items():
             if v is None:
@@ -94,7 +95,7 @@ def test_queue_kernel_on_ragged_tiny_and_wide_batches():
 
 def test_single_align_keeps_the_launch_per_evaluation_path_and_a_batch_of_one_can_use_the_queue(shard):
     tgt, sources, guesses, _ = shard
-    d = _reg({}, ndt_resolution=1.0)                               # default: batches of >= 2 pairs go through the queue kernel
+    d = _reg({}, ndt_resolution=1.0)                               # default: one launch per evaluation
     q1 = _reg({"DGS_NDT_QUEUE": "1", "DGS_NDT_QUEUE_MIN_PAIRS": "1"}, ndt_resolution=1.0)
     l1 = _reg({"DGS_NDT_QUEUE": "0", "DGS_NDT_SCHEDULE": "1"}, ndt_resolution=1.0)
     for r in (d, q1, l1):
