@@ -154,6 +154,7 @@ def main():
         distinct = min(args.distinct_scans * G, n_total) if G == 1 else min(args.distinct_scans, n_total)
         tgt, sources, guesses, gts = synth.loop_batch(n_candidates=n_total, n_points=args.points, seed=40, distinct_scans=distinct)
         new_kf, cands = keyframes(tgt, sources, guesses, on_device=False)
+        new_kf.cloud = torch.from_numpy(tgt).pin_memory()   # the new keyframe waits in pinned host memory: its upload inside the step is one DMA per member
         # the group keeps keyframes by id: scan s is shared by the candidates s, s + distinct, ... -> give those the id of the scan so
         # that each distinct scan is resident once (on member s mod G); the guesses stay per candidate
         for c, k in enumerate(cands):

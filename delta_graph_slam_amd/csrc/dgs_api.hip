@@ -35,15 +35,24 @@ int ensure_poll_events(dgs_handle* h) {
   return DGS_OK;
 }
 
+// The side stream is created together with the handle's own stream (dgs_create), not at first use: HIP deals streams to a small number
+// of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order, and two streams on one hardware queue run one after the
+// other.  Created back to back the two get neighbouring queues; created lazily -- after RCCL had made its streams for a dgs_group --
+// the side stream landed on the main stream's queue and the index build it should hide (0.9-1.2 ms) ran in line with the iterations
+// (measured: 3.48 ms per 32-candidate step against 2.36 ms; scripts/dbg_group_time.py).
+static int side_create(dgs_handle* h) {
+  if (h->side_stream) return DGS_OK;
+  // lowest priority: the side stream's small builds fill what the main stream's launches leave free, never the other way round
+  int prio_low = 0, prio_high = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  DGS_HIP_TRY(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_low));
+  DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  return DGS_OK;
+}
+
 int side_fork(dgs_handle* h) {
-  if (!h->side_stream) {
-    // lowest priority: the side stream's small builds fill what the main stream's launches leave free, never the other way round
-    int prio_low = 0, prio_high = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    DGS_HIP_TRY(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_low));
-    DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  }
+  if (side_create(h) != DGS_OK) return DGS_ERR_HIP;
   DGS_HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
   DGS_HIP_TRY(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
   return DGS_OK;
@@ -248,6 +257,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   }
   h->device = dev;
   h->own_stream = true;
+  (void)side_create(h);   // now, next to the main stream (see side_create); a failure here is retried at first use
   if (kExperiments)   // the product library carries neither the grid index nor the packed-FP32 kernel (measured losers: `make experiments`)
     if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;

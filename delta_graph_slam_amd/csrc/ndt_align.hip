@@ -93,6 +93,17 @@ struct NdtHdrRegs {
   __device__ __forceinline__ float H(int k, int c) const { return h[k * 3 + c]; }
 };
 
+// exp(x) for the default evaluation order: v_exp_f32 of x * log2(e) with the product's rounding error (and the low bits of log2 e)
+// folded back in -- within ~1 ulp of the exact value for every x whose result is a normal float, 0 / inf beyond, NaN for NaN --
+// in 6 instructions where the library expf takes 14 (its range reduction + ldexp buy correct subnormal results, which the NDT
+// weights never need: such a term is < 1e-38 of the sum).  The validation orders use det_expf (common.h).
+__device__ __forceinline__ float exp_hw(float x) {
+  const float t = x * 1.44269502e+0f;                                         // float(log2 e) = 0x3FB8AA3B
+  const float r = __builtin_fmaf(x, 1.92596299e-8f, __builtin_fmaf(x, 1.44269502e+0f, -t));   // x * log2 e - t, to ~2^-48 x
+  const float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 6.93147182e-1f, e);                            // 2^(t + r) = 2^t (1 + r ln 2 + ...)
+}
+
 template <int SEARCH, class HDR>
 __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& hdr, const bool need_h, const float4* __restrict__ src, const int n,
                                                const int first, const int stride, const VoxelGrid& g, const double gd1, const float gd2,
@@ -156,7 +167,7 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
       const float u0 = q0 * Cxx + q1 * Cxy + q2 * Cxz;
       const float u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
       const float u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
-      float e = expf(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
+      float e = exp_hw(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
       // gauss_d1 is a double upstream: float(double(e) * d1), not e * float(d1) -- the float constant alone would scale score,
       // gradient and Hessian by (1 + 2.8e-8) at 1 m resolution, which was the whole per-evaluation difference to a CPU run
       const float score_inc = (float)(-gd1 * (double)e);
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
         const v2f u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
         const v2f u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
         const v2f arg = -gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f;
-        v2f e = {expf(arg.x), expf(arg.y)};
+        v2f e = {exp_hw(arg.x), exp_hw(arg.y)};
         const float sia = (float)(-gd1 * (double)e.x), sib = (float)(-gd1 * (double)e.y);
         e = gd2 * e;
         const bool oka = va >= 0 && !(e.x > 1.f || e.x < 0.f || e.x != e.x), okb = vb >= 0 && !(e.y > 1.f || e.y < 0.f || e.y != e.y);
@@ -1589,9 +1600,17 @@ static void launch_solve(dgs_handle* h, const NdtLaunch& L) {
 static NdtLaunch choose_launch(int n_pairs, int max_n) {
   NdtLaunch L;
   L.n_pairs = n_pairs;
-  static const int env_cap = std::getenv("DGS_NDT_CAP") ? std::atoi(std::getenv("DGS_NDT_CAP")) : 128;          // tuning knobs (sweeps only)
+  // tuning knobs (sweeps only; the defaults are the measured winners: profiles/r03/launch_shape_sweep.jsonl)
+  static const int env_cap = std::getenv("DGS_NDT_CAP") ? std::atoi(std::getenv("DGS_NDT_CAP")) : 1024;
   static const int env_total = std::getenv("DGS_NDT_BLOCKS") ? std::atoi(std::getenv("DGS_NDT_BLOCKS")) : 1024;
-  L.cap_blocks = std::max(1, std::min((max_n + kBlock - 1) / kBlock, env_cap));             // at most 128 slices (partial rows) per pair
+  static const int env_ppt = std::getenv("DGS_NDT_PPT") ? std::max(1, std::atoi(std::getenv("DGS_NDT_PPT"))) : 2;
+  // Slices (= partial rows) one pair can get: sized by the cloud, >= env_ppt points per thread -- 128 workgroups for a 65,536-point
+  // scan as before, 391 for the 200,000-point indoor scan (which a fixed cap of 128 held on half of the 256 CUs), never more rows
+  // than the closing workgroup's row sum was laid out for.
+  static const int env_min = std::getenv("DGS_NDT_MIN_BLOCKS") ? std::max(1, std::atoi(std::getenv("DGS_NDT_MIN_BLOCKS"))) : 64;
+  const int by_points = (max_n + kBlock * env_ppt - 1) / (kBlock * env_ppt);
+  const int at_least = std::min(env_min, (max_n + kBlock - 1) / kBlock);   // small clouds: 64 workgroups while every thread still has a point (16,384 points: 13.3 against 15.1 us per evaluation)
+  L.cap_blocks = std::max(1, std::min({std::max(by_points, at_least), env_cap, kMaxPartialBlocks}));
   L.total_blocks = (int)std::max<int64_t>(n_pairs, std::min<int64_t>((int64_t)n_pairs * L.cap_blocks, env_total));  // ~4 workgroups per CU
   L.max_n = std::max(max_n, 1);
   L.queue_workers = 0;

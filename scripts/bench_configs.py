@@ -67,6 +67,12 @@ def ndt_pair(name, tgt, src, res, guess, reps, cpu, orc, threads):
            "gpu_ms_per_evaluation": 1e3 * t_align / max(ev, 1), "ndt_derivatives_us": 1e3 * ms / max(n, 1), "ndt_solve_us": 1e3 * ms_s / max(n_s, 1),
            "ndt_derivatives_GBps": bytes_eval * ev * reps / (ms * 1e-3) / 1e9 if ms > 0 else None, "valid_voxels": c["valid_voxels"],
            "gpu_registrations_per_s": 1.0 / t_align}
+    # the per-kernel roofline case "in isolation" -- one pair, every launch is one evaluation of it
+    ach = bytes_eval * n / (ms * 1e-3) / 1e9 if ms > 0 else None
+    out["roofline"] = {"bound": "hbm", "kernel": "ndt_derivatives_kernel<DIRECT7, fused> (one pair: derivatives + the optimiser step in the closing workgroup)",
+                       "algorithmic_bytes_per_launch": bytes_eval, "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1), "achieved": ach, "peak": 8000.0,
+                       "unit": "GB/s", "frac": ach / 8000.0 if ach else None, "traffic": None,
+                       "points_per_s": src.shape[0] * n / (ms * 1e-3) if ms > 0 else None}
     if cpu:
         o = orc.NdtOracle(resolution=res, num_threads=threads)
         o.set_target(tgt)
@@ -146,6 +152,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--only-ndt", action="store_true", help="the three single-pair NDT rows only (launch-shape sweeps: DGS_NDT_PPT / DGS_NDT_CAP / DGS_NDT_BLOCKS)")
     args = ap.parse_args()
     import torch
     from delta_graph_slam_amd import synth
@@ -165,12 +172,15 @@ def main():
     g[1, 3] += 0.10
     print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, odometry-like guess (0.27 m off)", tgt, src, 1.0, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
 
-    print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_GICP dmax 2.5, odometry-like guess", "FAST_GICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
-    print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_VGICP res 1.0 DIRECT1, odometry-like guess", "FAST_VGICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th, vgicp_resolution=1.0)), flush=True)
+    if not args.only_ndt:
+      print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_GICP dmax 2.5, odometry-like guess", "FAST_GICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
+      print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_VGICP res 1.0 DIRECT1, odometry-like guess", "FAST_VGICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th, vgicp_resolution=1.0)), flush=True)
 
     tgt, src, Tgt = synth.indoor_pair()
     print(json.dumps(ndt_pair("cfg5 indoor 200k pair, NDT 0.5 m, identity guess", tgt, src, 0.5, None, max(3, args.reps // 2), cpu, orc, th)), flush=True)
 
+    if args.only_ndt:
+        return
     # ---- cfg3: VLP-16 stream through the odometry driver, FAST_GICP with the launch-file values
     clouds, poses = synth.vlp16_stream(n_frames=args.frames)
     dclouds = [torch.from_numpy(c).cuda() for c in clouds]
