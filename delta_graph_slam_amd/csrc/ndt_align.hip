@@ -886,7 +886,7 @@ __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtPair* hdr, NdtSo
     if (SVD_REGS) svd_solve6_regs_dev(s.hess, neg_g, delta, 1e-17, 60);
     else svd_solve6_dev(s.hess, neg_g, delta, 1e-17, 60);
   } else {
-    gj_solve6_wave(s.hess, neg_g, delta, &rc);
+    gj_solve6_uniform(s.hess, s.grad, delta, &rc);
     if (!(rc > 1e-13)) svd_solve6_dev(s.hess, neg_g, delta);
   }
 #ifdef DGS_CLOSE_STAMPS
@@ -1102,19 +1102,22 @@ __device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* 
   if (threadIdx.x >= kWave) return false;
   // ---- one wave advances the optimiser: every lane computes the same values, lane 0 writes the pair's record
   const bool writer = threadIdx.x == 0;
-  s.score = tot[0];
-#pragma unroll
-  for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];
-  if (need_h) {
-    int q = 7;
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = i; j < 6; j++) {
-        s.hess[i * 6 + j] = tot[q];
-        s.hess[j * 6 + i] = tot[q];
-        q++;
+  // the totals into the optimiser state, one entry per lane: lanes 0..35 the symmetric Hessian (entry (i, j) <- upper-triangle slot of
+  // (min, max)), 36..41 the gradient, 42 the score (all 64 lanes storing all 49 entries one after the other cost 0.7 us)
+  {
+    const int t = threadIdx.x;
+    if (t < 36) {
+      if (need_h) {
+        const int i = t / 6, j = t % 6, lo = min(i, j), hi = max(i, j);
+        s.hess[t] = tot[7 + lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
       }
+    } else if (t < 42) {
+      s.grad[t - 36] = tot[1 + t - 36];
+    } else if (t == 42) {
+      s.score = tot[0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS stores have landed
   }
   CLOSE_STAMP(2)
   ndt_advance<false, QUEUE>(st, hdr_next ? hdr_next : st, s, c, writer);

@@ -48,6 +48,58 @@ __device__ __forceinline__ void gj_solve6_wave(const double* A, const double* b,
   *rcond = (pmax > 0) ? pmin / pmax : 0.0;
 }
 
+// The same elimination with EVERY lane holding the whole 6 x 7 system in registers and computing the same values (the optimiser runs
+// wave-uniform anyway): no cross-lane traffic at all.  The lane-per-element form above pays, per pivot, twelve v_readlane, six
+// ds_bpermute round trips through the LDS crossbar and two double divisions on its critical path -- 3.5 us per Newton step at the
+// end of every fused NDT launch (scripts/dbg_close_stamps.py), a third of the launch's serial tail; this one pays ~105 FMAs, 27
+// multiplications and 6 reciprocals.  Row pivoting as above (largest |entry| of the column among the rows not yet used); the pivot
+// row is scaled by the reciprocal of the pivot instead of dividing every entry, so the result differs from the form above in the last
+// bits (both are within cond * 1e-16 of the exact solution).  A: row-major 6 x 6, g: the system solved is A x = -g.
+__device__ __forceinline__ void gj_solve6_uniform(const double* __restrict__ A, const double* __restrict__ g, double* x, double* rcond) {
+  double M[6][7];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) M[r][c] = A[r * 6 + c];
+    M[r][6] = -g[r];
+  }
+  double pmax = 0.0, pmin = DBL_MAX;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    int best = k;
+    double bv = fabs(M[k][k]);
+#pragma unroll
+    for (int r = k + 1; r < 6; r++) {
+      const double v = fabs(M[r][k]);
+      if (v > bv) { bv = v; best = r; }
+    }
+#pragma unroll
+    for (int r = k + 1; r < 6; r++)
+      if (best == r) {
+#pragma unroll
+        for (int c = k; c < 7; c++) { const double t = M[k][c]; M[k][c] = M[r][c]; M[r][c] = t; }
+      }
+    const double piv = M[k][k];
+    pmax = fmax(pmax, fabs(piv));
+    pmin = fmin(pmin, fabs(piv));
+    if (piv != 0.0) {
+      const double inv = 1.0 / piv;
+#pragma unroll
+      for (int c = k + 1; c < 7; c++) M[k][c] *= inv;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        if (r == k) continue;
+        const double f = M[r][k];
+#pragma unroll
+        for (int c = k + 1; c < 7; c++) M[r][c] -= f * M[k][c];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) x[r] = M[r][6];
+  *rcond = (pmax > 0) ? pmin / pmax : 0.0;
+}
+
 // Pseudo-inverse solve through a one-sided Jacobi SVD with Eigen::JacobiSVD's default rank threshold
 // (6 * eps * s_max).  Slow path: only taken when the elimination above meets a (numerically) singular Hessian -- and the
 // Newton solve of the NDT validation modes (ndt_strict_order), which run it with skip_tol 1e-17 / 60 sweeps: then every
