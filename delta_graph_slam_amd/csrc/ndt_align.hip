@@ -886,7 +886,7 @@ __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtPair* hdr, NdtSo
     if (SVD_REGS) svd_solve6_regs_dev(s.hess, neg_g, delta, 1e-17, 60);
     else svd_solve6_dev(s.hess, neg_g, delta, 1e-17, 60);
   } else {
-    gj_solve6_uniform(s.hess, s.grad, delta, &rc);
+    gj_solve6_columns(s.hess, s.grad, delta, &rc);
     if (!(rc > 1e-13)) svd_solve6_dev(s.hess, neg_g, delta);
   }
 #ifdef DGS_CLOSE_STAMPS

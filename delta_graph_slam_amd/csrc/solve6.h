@@ -48,55 +48,52 @@ __device__ __forceinline__ void gj_solve6_wave(const double* A, const double* b,
   *rcond = (pmax > 0) ? pmin / pmax : 0.0;
 }
 
-// The same elimination with EVERY lane holding the whole 6 x 7 system in registers and computing the same values (the optimiser runs
-// wave-uniform anyway): no cross-lane traffic at all.  The lane-per-element form above pays, per pivot, twelve v_readlane, six
-// ds_bpermute round trips through the LDS crossbar and two double divisions on its critical path -- 3.5 us per Newton step at the
-// end of every fused NDT launch (scripts/dbg_close_stamps.py), a third of the launch's serial tail; this one pays ~105 FMAs, 27
-// multiplications and 6 reciprocals.  Row pivoting as above (largest |entry| of the column among the rows not yet used); the pivot
-// row is scaled by the reciprocal of the pivot instead of dividing every entry, so the result differs from the form above in the last
-// bits (both are within cond * 1e-16 of the exact solution).  A: row-major 6 x 6, g: the system solved is A x = -g.
-__device__ __forceinline__ void gj_solve6_uniform(const double* __restrict__ A, const double* __restrict__ g, double* x, double* rcond) {
-  double M[6][7];
+// Gauss-Jordan with row pivoting, ONE COLUMN PER LANE: lanes 0..5 hold the columns of A, lane 6 the right-hand side -g, six doubles each,
+// in registers.  The pivot search of column k is local to lane k (it owns the whole column), a row exchange is local to every lane,
+// and what crosses lanes per pivot is the pivot row index, the pivot and the five multipliers -- v_readlane broadcasts from lane k,
+// no LDS crossbar, no division per element (one reciprocal, computed by every lane).  ~50 instructions per pivot on a 12-register
+// state, against the lane-per-element form above with its six ds_bpermute round trips and two divisions per pivot (3.5 us per Newton
+// step at the end of every fused NDT launch, scripts/dbg_close_stamps.py) and against a whole-system-per-lane form, whose 84
+// registers spill under the fused kernel's 128-VGPR budget (3.1 us).  Same pivoting rule as above; the pivot row is scaled by the
+// reciprocal of the pivot, so the result differs from the form above in the last bits (both within cond * 1e-16 of the exact
+// solution).  A: row-major 6 x 6 (any memory), g: the system solved is A x = -g; every lane receives x.
+__device__ __forceinline__ void gj_solve6_columns(const double* __restrict__ A, const double* __restrict__ g, double* x, double* rcond) {
+  const int lane = threadIdx.x & 63;
+  const int col = lane < 7 ? lane : 6;   // lanes 7.. mirror lane 6 (idle copies)
+  double a[6];
 #pragma unroll
-  for (int r = 0; r < 6; r++) {
-#pragma unroll
-    for (int c = 0; c < 6; c++) M[r][c] = A[r * 6 + c];
-    M[r][6] = -g[r];
-  }
+  for (int r = 0; r < 6; r++) a[r] = (col < 6) ? A[r * 6 + col] : -g[r];
   double pmax = 0.0, pmin = DBL_MAX;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
+    // lane k: the row (>= k) with the largest |entry| of its column
     int best = k;
-    double bv = fabs(M[k][k]);
+    double bv = fabs(a[k]);
 #pragma unroll
     for (int r = k + 1; r < 6; r++) {
-      const double v = fabs(M[r][k]);
+      const double v = fabs(a[r]);
       if (v > bv) { bv = v; best = r; }
     }
+    best = __builtin_amdgcn_readlane(best, k);
 #pragma unroll
     for (int r = k + 1; r < 6; r++)
-      if (best == r) {
-#pragma unroll
-        for (int c = k; c < 7; c++) { const double t = M[k][c]; M[k][c] = M[r][c]; M[r][c] = t; }
-      }
-    const double piv = M[k][k];
+      if (best == r) { const double t = a[k]; a[k] = a[r]; a[r] = t; }   // wave-uniform: every lane exchanges the same two rows
+    const double piv = readlane_f64(a[k], k);
     pmax = fmax(pmax, fabs(piv));
     pmin = fmin(pmin, fabs(piv));
     if (piv != 0.0) {
       const double inv = 1.0 / piv;
+      double f[6];
 #pragma unroll
-      for (int c = k + 1; c < 7; c++) M[k][c] *= inv;
+      for (int r = 0; r < 6; r++) f[r] = (r == k) ? 0.0 : readlane_f64(a[r], k);   // column k before the update = the multipliers * piv
+      a[k] *= inv;
 #pragma unroll
-      for (int r = 0; r < 6; r++) {
-        if (r == k) continue;
-        const double f = M[r][k];
-#pragma unroll
-        for (int c = k + 1; c < 7; c++) M[r][c] -= f * M[k][c];
-      }
+      for (int r = 0; r < 6; r++)
+        if (r != k) a[r] -= f[r] * a[k];
     }
   }
 #pragma unroll
-  for (int r = 0; r < 6; r++) x[r] = M[r][6];
+  for (int r = 0; r < 6; r++) x[r] = readlane_f64(a[r], 6);
   *rcond = (pmax > 0) ? pmin / pmax : 0.0;
 }
 

@@ -1,7 +1,6 @@
 # SQ / cache counters per kernel for the bench workload: separate rocprofv3 --pmc passes (--kernel-trace only, as the pool requires),
 # summarised by scripts/pmc_summarise.py.  usage on the GPU box (repo root): bash scripts/pmc_round.sh <prefix> [script args...]
 # (default workload: bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-traffic; PMC_CMD="scripts/dbg_strict_profile.py" profiles another script)
-set -e
 P=${1:-x}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -18,4 +17,5 @@ for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCL
 done
 cd $R
 python3 scripts/pmc_summarise.py $OUT > gpurun_out/${P}_pmc_per_kernel.json
+rm -rf $OUT   # raw per-dispatch counter files: tens of MB per pass
 echo summary-done
