@@ -464,10 +464,12 @@ def parity_legs(args, cpu, records, value, cands, new_kf, tgt, sources, reg_kw, 
     inside = (e[:, 0] <= TOL_M) & (e[:, 1] <= TOL_RAD)
     outside = []
     for c in np.nonzero(~inside)[0]:
-        # the oracle's own band on this pair: its answer under perturbations that carry no information (FMA build, libm expf, +-1 / 2 ulp guess)
-        _, bt, br = orc.ndt_band(tgt, sources[c], LoopDetector.guess_for(new_kf, cands[c]), resolution=args.resolution)
+        # the oracle's own band on this pair: the largest move of ITS answer under perturbations that carry no information -- the FMA build,
+        # libm's expf, and the float32 guess moved by +-1 .. +-16 ulps (34 twins; six twins underestimate it: scripts/dbg_gate_bands.py)
+        twins = ((True, 0, 0), (False, 1, 0)) + tuple((False, 0, k) for k in range(-16, 17) if k)
+        _, bt, br = orc.ndt_band(tgt, sources[c], LoopDetector.guess_for(new_kf, cands[c]), twins=twins, resolution=args.resolution)
         outside.append({"pair": int(c), "translation_m": float(e[c, 0]), "rotation_rad": float(e[c, 1]), "oracle_band_m": float(bt),
-                        "oracle_band_rad": float(br), "inside_oracle_band": bool(e[c, 0] <= bt + TOL_M and e[c, 1] <= br + TOL_RAD)})
+                        "oracle_band_rad": float(br), "oracle_band_twins": 34, "inside_oracle_band": bool(e[c, 0] <= bt + TOL_M and e[c, 1] <= br + TOL_RAD)})
     conv_cpu, fit_cpu = cpu["converged"][:n_cmp], cpu["fitness"][:n_cmp]
     b_ref, s_ref = sequential_best(conv_cpu, fit_cpu)
     b_gpu, s_gpu = sequential_best(records[:n_cmp, 1] > 0.5, records[:n_cmp, 2])

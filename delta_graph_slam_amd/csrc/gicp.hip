@@ -574,10 +574,7 @@ __device__ __forceinline__ void gicp_queue(GicpPair* st, const double* T, int ki
 }
 
 __device__ __forceinline__ void gicp_try_lm(GicpPair* st, GicpSolver& s, const GicpConsts& c, bool writer) {
-  double Hl[36], nb[6];
-  for (int k = 0; k < 36; k++) Hl[k] = s.H[k];
-  for (int k = 0; k < 6; k++) { Hl[k * 6 + k] += s.lambda; nb[k] = -s.b[k]; }
-  solve6_wave(Hl, nb, s.d);
+  solve6_step(s.H, s.b, s.lambda, s.d);
   se3_exp_dev(s.d, s.delta);
   iso_mul(s.delta, s.x0, s.xi);
   gicp_queue(st, s.xi, 1, writer);
@@ -605,9 +602,7 @@ __device__ __forceinline__ void gicp_advance(GicpPair* st, GicpSolver& s, const 
   }
   if (s.phase == GP_LINEARIZE_WAIT) {
     if (c.optimizer == DGS_GICP_OPT_GAUSS_NEWTON) {
-      double nb[6];
-      for (int k = 0; k < 6; k++) nb[k] = -s.b[k];
-      solve6_wave(s.H, nb, s.d);
+      solve6_step(s.H, s.b, 0.0, s.d);
       se3_exp_dev(s.d, s.delta);
       iso_mul(s.delta, s.x0, s.x0);
       gicp_after_step(st, s, c, writer);

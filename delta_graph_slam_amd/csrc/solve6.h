@@ -56,13 +56,13 @@ __device__ __forceinline__ void gj_solve6_wave(const double* A, const double* b,
 // step at the end of every fused NDT launch, scripts/dbg_close_stamps.py) and against a whole-system-per-lane form, whose 84
 // registers spill under the fused kernel's 128-VGPR budget (3.1 us).  Same pivoting rule as above; the pivot row is scaled by the
 // reciprocal of the pivot, so the result differs from the form above in the last bits (both within cond * 1e-16 of the exact
-// solution).  A: row-major 6 x 6 (any memory), g: the system solved is A x = -g; every lane receives x.
-__device__ __forceinline__ void gj_solve6_columns(const double* __restrict__ A, const double* __restrict__ g, double* x, double* rcond) {
+// solution).  A: row-major 6 x 6 (any memory), g: the system solved is (A + diag_add I) x = -g; every lane receives x.
+__device__ __forceinline__ void gj_solve6_columns(const double* __restrict__ A, const double* __restrict__ g, double* x, double* rcond, const double diag_add = 0.0) {
   const int lane = threadIdx.x & 63;
   const int col = lane < 7 ? lane : 6;   // lanes 7.. mirror lane 6 (idle copies)
   double a[6];
 #pragma unroll
-  for (int r = 0; r < 6; r++) a[r] = (col < 6) ? A[r * 6 + col] : -g[r];
+  for (int r = 0; r < 6; r++) a[r] = (col < 6) ? (r == col ? A[r * 6 + col] + diag_add : A[r * 6 + col]) : -g[r];
   double pmax = 0.0, pmin = DBL_MAX;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
@@ -211,6 +211,18 @@ __device__ __forceinline__ void solve6_wave(const double* A, const double* b, do
   double rc;
   gj_solve6_wave(A, b, x, &rc);
   if (!(rc > 1e-13)) svd_solve6_dev(A, b, x);
+}
+
+// x = -(H + lambda I)^-1 g: the Gauss-Newton / Levenberg-Marquardt step of the GICP optimisers, through the column-per-lane elimination
+__device__ __forceinline__ void solve6_step(const double* H, const double* g, const double lambda, double* x) {
+  double rc;
+  gj_solve6_columns(H, g, x, &rc, lambda);
+  if (!(rc > 1e-13)) {
+    double Hl[36], nb[6];
+    for (int k = 0; k < 36; k++) Hl[k] = H[k];
+    for (int k = 0; k < 6; k++) { Hl[k * 6 + k] += lambda; nb[k] = -g[k]; }
+    svd_solve6_dev(Hl, nb, x);
+  }
 }
 
 }  // namespace dgs
