@@ -49,7 +49,7 @@ class Result(C.Structure):
 SYMBOLS = [
     "dgs_params_init", "dgs_create", "dgs_destroy", "dgs_last_error", "dgs_abi_version", "dgs_set_stream",
     "dgs_synchronize", "dgs_set_input_target", "dgs_set_input_source", "dgs_align", "dgs_get_fitness_score",
-    "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_nn_fitness_distances", "dgs_align_batch", "dgs_calc_fitness_score", "dgs_voxel_grid_filter", "dgs_approx_voxel_grid_filter", "dgs_cloud_create", "dgs_cloud_destroy", "dgs_cloud_size",
+    "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_nn_fitness_distances", "dgs_align_batch", "dgs_find_loop_candidates", "dgs_calc_fitness_score", "dgs_voxel_grid_filter", "dgs_approx_voxel_grid_filter", "dgs_cloud_create", "dgs_cloud_destroy", "dgs_cloud_size",
     "dgs_set_input_target_cloud", "dgs_set_input_source_cloud", "dgs_align_batch_clouds", "dgs_profile_enable",
     "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_get_voxels",
     "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize", "dgs_vgicp_get_voxels",
@@ -92,6 +92,8 @@ def load(path=None):
     lib.dgs_nn_fitness_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.dgs_align_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                     C.c_double, P(Result)]
+    lib.dgs_find_loop_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
+                                             C.c_int64, P(C.c_int64)]
     lib.dgs_calc_fitness_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_double, P(C.c_double)]
     lib.dgs_voxel_grid_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_int32, P(C.c_int64)]
     lib.dgs_approx_voxel_grid_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_int32, P(C.c_int64)]

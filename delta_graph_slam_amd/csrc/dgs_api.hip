@@ -139,6 +139,43 @@ int transform_cloud(dgs_handle* h, const float4* in, float4* out, int64_t n, con
 
 }  // namespace dgs
 
+// LoopDetector::find_candidates: one workgroup walks the keyframes 1,024 at a time and writes the indices that pass both tests in
+// keyframe order (wave ballots + a running base: an ordered compaction without atomics)
+__global__ __launch_bounds__(1024) void find_candidates_kernel(const double* __restrict__ accum, const double* __restrict__ xy, const long long n,
+                                                               const double new_accum, const double nx, const double ny, const double accum_thresh,
+                                                               const double dist_thresh, int* __restrict__ out, const long long capacity,
+                                                               long long* __restrict__ n_out) {
+#pragma clang fp contract(off)
+  __shared__ int wave_count[16];
+  __shared__ long long base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (long long i0 = 0; i0 < n; i0 += 1024) {
+    const long long i = i0 + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+      const double dx = xy[2 * i] - nx, dy = xy[2 * i + 1] - ny;
+      keep = !(new_accum - accum[i] < accum_thresh) && !(sqrt(dx * dx + dy * dy) > dist_thresh);   // the reference's two `continue`s, negated
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wave_count[wave] = __popcll(m);
+    __syncthreads();
+    long long pos = base;
+    for (int w = 0; w < wave; w++) pos += wave_count[w];
+    pos += __popcll(m & ((1ull << lane) - 1ull));
+    if (keep && pos < capacity) out[pos] = (int)i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long t = 0;
+      for (int w = 0; w < 16; w++) t += wave_count[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = base;
+}
+
 static int set_device(dgs_handle* h) {
   DGS_HIP_TRY(h, hipSetDevice(h->device));
   return DGS_OK;
@@ -776,6 +813,46 @@ int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, doubl
   if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
   if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
   return ndt_probe(h, p6, T16, score, grad6, hess36);
+}
+
+int dgs_find_loop_candidates(dgs_handle* h, const double* accum_distance, const double* xy, int64_t n, int32_t on_device, double new_accum_distance,
+                             const double* new_xy, double accum_distance_thresh, double distance_thresh, int32_t* indices, int64_t capacity, int64_t* n_out) {
+  if (!h || !n_out || !new_xy || n < 0 || capacity < 0 || (n > 0 && (!accum_distance || !xy)) || (capacity > 0 && !indices) || n > INT32_MAX) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  *n_out = 0;
+  if (n == 0) return DGS_OK;
+  // staging: [accum n | xy 2n] doubles, [indices cap] ints, one count
+  DevBuf<double> din;
+  DevBuf<int> dout;
+  DevBuf<long long> dcnt;
+  const double* d_acc = accum_distance;
+  const double* d_xy = xy;
+  int* d_idx = indices;
+  const int64_t cap = on_device ? capacity : std::min<int64_t>(capacity, n);
+  int rc = DGS_OK;
+  if (dcnt.reserve(1) != hipSuccess) { h->err = "hipMalloc failed"; return DGS_ERR_HIP; }
+  if (!on_device) {
+    if (din.reserve((size_t)3 * n) != hipSuccess || dout.reserve((size_t)std::max<int64_t>(cap, 1)) != hipSuccess) { h->err = "hipMalloc failed"; rc = DGS_ERR_HIP; }
+    if (!rc && (hipMemcpyAsync(din.ptr, accum_distance, sizeof(double) * n, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync(din.ptr + n, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, h->stream) != hipSuccess)) { h->err = "hipMemcpyAsync failed"; rc = DGS_ERR_HIP; }
+    d_acc = din.ptr; d_xy = din.ptr + n; d_idx = dout.ptr;
+  }
+  long long count = 0;
+  if (!rc) {
+    hipLaunchKernelGGL(find_candidates_kernel, dim3(1), dim3(1024), 0, h->stream, d_acc, d_xy, (long long)n, new_accum_distance, new_xy[0], new_xy[1],
+                       accum_distance_thresh, distance_thresh, d_idx, (long long)cap, dcnt.ptr);
+    if (hipMemcpyAsync(&count, dcnt.ptr, sizeof(count), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipGetLastError() != hipSuccess) { h->err = "find_candidates_kernel failed"; rc = DGS_ERR_HIP; }
+  }
+  if (!rc) {
+    *n_out = count;
+    if (count > capacity) { h->err = "indices buffer too small for the candidates"; rc = DGS_ERR_INVALID_ARGUMENT; }
+    else if (!on_device && count > 0 && hipMemcpy(indices, d_idx, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "hipMemcpy failed"; rc = DGS_ERR_HIP; }
+  }
+  (void)hipStreamSynchronize(h->stream);
+  din.release(); dout.release(); dcnt.release();
+  return rc;
 }
 
 int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const float* cloud2, int64_t n2, int32_t on_device,

@@ -58,7 +58,7 @@ class Loop:
 
 class LoopDetector:
     def __init__(self, params: Optional[dict] = None, registration=None, group=None, device: Optional[int] = None,
-                 cache_clouds: bool = False):
+                 cache_clouds: bool = False, filter_on_device: bool = False):
         pr = dict(params or {})
         self.distance_thresh = float(pr.get("distance_thresh", 5.0))
         self.accum_distance_thresh = float(pr.get("accum_distance_thresh", 8.0))
@@ -75,6 +75,7 @@ class LoopDetector:
         # keyframe id -> DeviceCloud: a keyframe that is a candidate tick after tick (delta_graph_slam_nodelet.cpp:816 calls
         # detect() every graph_update_interval) is uploaded and indexed once; needs KeyFrame.id to be unique
         self.cache_clouds = bool(cache_clouds)
+        self.filter_on_device = bool(filter_on_device)   # find_candidates through dgs_find_loop_candidates (second half)
         self._cloud_cache = {}
 
     def resident(self, keyframe: "KeyFrame", as_target: bool = False):
@@ -108,6 +109,13 @@ class LoopDetector:
     def find_candidates(self, keyframes: Sequence[KeyFrame], new_keyframe: KeyFrame) -> List[KeyFrame]:
         if new_keyframe.accum_distance - self.last_edge_accum_distance < self.distance_from_last_edge_thresh:
             return []
+        if self.filter_on_device and len(keyframes) and hasattr(self.registration, "find_loop_candidates"):
+            # the same two tests over all keyframes in one device call (dgs_find_loop_candidates); keyframe order is kept
+            acc = np.array([k.accum_distance for k in keyframes], np.float64)
+            xy = np.array([np.asarray(k.estimate, np.float64)[:2, 2] for k in keyframes], np.float64)
+            idx = self.registration.find_loop_candidates(acc, xy, new_keyframe.accum_distance, np.asarray(new_keyframe.estimate, np.float64)[:2, 2],
+                                                         self.accum_distance_thresh, self.distance_thresh)
+            return [keyframes[i] for i in idx]
         out = []
         p2 = np.asarray(new_keyframe.estimate, np.float64)[:2, 2]
         for k in keyframes:

@@ -235,6 +235,19 @@ class Registration:
         self._check(self._lib.dgs_nn_fitness_distances(self._h, ptr, m, 0, sq.ctypes.data_as(C.c_void_p)))
         return sq
 
+    def find_loop_candidates(self, accum_distance, xy, new_accum_distance: float, new_xy, accum_distance_thresh: float, distance_thresh: float) -> np.ndarray:
+        """LoopDetector::find_candidates (loop_detector.hpp:83-111) on the device: indices of the candidate keyframes, in keyframe order."""
+        acc = np.ascontiguousarray(accum_distance, dtype=np.float64)
+        p = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        q = np.ascontiguousarray(new_xy, dtype=np.float64)
+        n = acc.shape[0]
+        out = np.empty(max(n, 1), dtype=np.int32)
+        m = C.c_int64(0)
+        self._check(self._lib.dgs_find_loop_candidates(self._h, acc.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p), n, 0, float(new_accum_distance),
+                                                       q.ctypes.data_as(C.c_void_p), float(accum_distance_thresh), float(distance_thresh),
+                                                       out.ctypes.data_as(C.c_void_p), n, C.byref(m)))
+        return out[:m.value].copy()
+
     def calc_fitness_score(self, cloud1, cloud2, relpose=None, max_range: float = 1.7976931348623157e308) -> float:
         """InformationMatrixCalculator::calc_fitness_score (information_matrix_calculator.cpp:77-108) on the device."""
         p1, n1, d1, k1 = _cloud_ptr(cloud1)

@@ -199,6 +199,17 @@ int dgs_set_input_source_cloud(dgs_handle* h, dgs_cloud* cloud);
 int dgs_align_batch_clouds(dgs_handle* h, int32_t n, dgs_cloud* const* sources, const float* guesses16, int32_t compute_fitness,
                            double fitness_max_range, dgs_result* results);
 
+/* LoopDetector::find_candidates (/root/reference/include/hdl_graph_slam/loop_detector.hpp:83-111) over n keyframes on the device
+ * (second half): keyframe i is a candidate iff
+ *   new_accum_distance - accum_distance[i] >= accum_distance_thresh            (:93-96: "traveled distance ... too small" skips)
+ *   and sqrt(dx * dx + dy * dy) <= distance_thresh, (dx, dy) = xy[i] - new_xy  (:98-105: Eigen's norm() of the 2-D difference, double)
+ * `xy` holds n pairs (x, y) = node->estimate().translation().head<2>().  `indices` receives the candidates' positions in KEYFRAME ORDER
+ * (the order matters: loop_detector.hpp:149 breaks score ties in favour of the later candidate); *n_out is always the full count,
+ * DGS_ERR_INVALID_ARGUMENT when it exceeds `capacity`.  The "too close to the last loop edge" test (:85-87) stays with the caller.
+ * Poses change at every graph optimisation, so the arrays travel with the call (host pointers, or device pointers with on_device). */
+int dgs_find_loop_candidates(dgs_handle* h, const double* accum_distance, const double* xy, int64_t n, int32_t on_device, double new_accum_distance,
+                             const double* new_xy, double accum_distance_thresh, double distance_thresh, int32_t* indices, int64_t capacity, int64_t* n_out);
+
 /* InformationMatrixCalculator::calc_fitness_score(cloud1, cloud2, relpose, max_range)
  * (/root/reference/src/hdl_graph_slam/information_matrix_calculator.cpp:77-108; called per odometry edge and per loop
  * edge, apps/delta_graph_slam_nodelet.cpp:572,820): exact-NN index over cloud1, cloud2 transformed by the float cast of

@@ -137,3 +137,37 @@ def test_destroying_a_bound_cloud_detaches_it():
     r.setInputSource(src)
     r.align()
     assert r.hasConverged()
+
+
+def test_find_candidates_on_the_device_equals_the_reference_loop():
+    """dgs_find_loop_candidates == LoopDetector::find_candidates (loop_detector.hpp:83-111): the same keyframes in the same order,
+    including keyframes that sit exactly on either threshold, for a few hundred thousand keyframes as well as for none."""
+    from delta_graph_slam_amd.loop_detector import KeyFrame, LoopDetector
+    from delta_graph_slam_amd.registration import Registration
+    rng = np.random.default_rng(5)
+    reg = Registration("NDT_OMP")
+    for n in (0, 1, 63, 64, 65, 1023, 1025, 5000):
+        kfs = []
+        for i in range(n):
+            e = np.eye(3)
+            e[:2, 2] = rng.uniform(-12, 12, 2)
+            kfs.append(KeyFrame(None, e, float(rng.uniform(0, 60)), i))
+        new = KeyFrame(None, np.eye(3), 40.0, n)
+        new.estimate[:2, 2] = [1.5, -0.5]
+        if n >= 64:   # exactly on the thresholds: accum difference == 8 is kept (`<` skips), distance == 5 is kept (`>` skips)
+            kfs[10].accum_distance = 32.0
+            kfs[10].estimate[:2, 2] = [1.5 + 3.0, -0.5 + 4.0]
+            kfs[11].accum_distance = np.nextafter(32.0, 100.0)
+            kfs[11].estimate[:2, 2] = [1.5, -0.5]
+        host = LoopDetector({}, registration=reg)
+        dev = LoopDetector({}, registration=reg, filter_on_device=True)
+        a, b = host.find_candidates(kfs, new), dev.find_candidates(kfs, new)
+        assert [k.id for k in a] == [k.id for k in b], n
+        if n >= 64:
+            assert 10 in [k.id for k in b] and 11 not in [k.id for k in b]
+    big = 300000
+    acc = rng.uniform(0, 60, big)
+    xy = rng.uniform(-12, 12, (big, 2))
+    idx = reg.find_loop_candidates(acc, xy, 40.0, [1.5, -0.5], 8.0, 5.0)
+    want = np.nonzero(~(40.0 - acc < 8.0) & ~(np.sqrt((xy[:, 0] - 1.5) ** 2 + (xy[:, 1] + 0.5) ** 2) > 5.0))[0]
+    assert np.array_equal(idx, want)
