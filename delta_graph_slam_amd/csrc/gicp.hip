@@ -68,7 +68,7 @@ __device__ void regularize_cov(const double* cov9, int method, double* out6) {
 // groups walk nearly the same nodes), and each round's searches start from a bound on the k-th distance taken from the previous
 // round: all k neighbours of q' lie within r_k(q') + |q - q'| of q (pruning only: same sets).  It writes the set of every
 // point to `nbr` (slot r * 8 + sub of the 8-lane group -> nbr[pos * 32 + slot], -1 = nothing found).  (2)
-// gicp_cov_from_knn_kernel: 8 lanes per point gather the neighbours and reduce mean and covariance in double.
+// gicp_cov_from_knn_kernel: 8 lanes per point gather the neighbours and reduce mean and covariance in double; one lane per point regularises.
 __global__ __launch_bounds__(kBlock) void gicp_knn_kernel(const BvhView b, const int n, const int k, const int run, int* __restrict__ nbr) {
   const int sub = threadIdx.x & 7;
   const int wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
@@ -114,7 +114,10 @@ __global__ __launch_bounds__(kBlock) void gicp_knn_kernel(const BvhView b, const
 // exact answer among them (every point within s T_j sits in a gathered leaf); s is bisected between "overflows" and "too few
 // points" until every query of the leaf is answered.  Only what still fails after kKnnRetries -- or is irregular: fewer than 8
 // leaves, a non-finite point in the window, fewer than k finite window points -- takes the per-query walk.
-constexpr int kLeafCap = 64, kFrontCap = 64, kLeafChunks = kLeafCap / 8, kKnnRetries = 12;
+#ifndef DGS_KNN_LEAF_CAP
+#define DGS_KNN_LEAF_CAP 64
+#endif
+constexpr int kLeafCap = DGS_KNN_LEAF_CAP, kFrontCap = 64, kLeafChunks = kLeafCap / 8, kKnnRetries = 12;
 constexpr unsigned kInfBits = 0x7F800000u;
 
 __device__ __forceinline__ float readlane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -123,32 +126,128 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) { return (int)_
 // k-th smallest (1-based) of the wave's values d[0 .. chunks) (bit patterns of non-negative floats, kInfBits = none), built from
 // the top bit down: V keeps the largest prefix with fewer than k values below it.  If some prefix has EXACTLY k values below it
 // the descent stops there and returns it with lt_only = true: then { d < V } is the answer set and ties cannot matter.
+// `upper`: bit pattern of a value known to be >= the k-th smallest (0 = nothing known).  The descent is scalar work -- a compare,
+// a population count and a branch per chunk and bit, ~18 rounds per call on scan data, two thirds of this kernel's instructions -- and
+// its first eight rounds only find the binade of the answer: with a bound, the binades at and just below the bound's are tried
+// directly (one round each) and the descent starts at the mantissa.
 template <int NC>
-__device__ __forceinline__ unsigned kth_smallest_bits(const unsigned (&d)[NC], const int chunks, const int k, bool& lt_only) {
-  unsigned V = 0;
-  lt_only = false;
-#pragma unroll 1
-  for (int bit = 30; bit >= 0; bit--) {
-    const unsigned trial = V | (1u << bit);
-    int cnt = 0;
+__device__ __forceinline__ int count_below(const unsigned (&d)[NC], const int chunks, const unsigned trial) {
+  int cnt = 0;
 #pragma unroll
-    for (int c = 0; c < NC; c++)
-      if (c < chunks) cnt += __popcll(__ballot(d[c] < trial));
+  for (int c = 0; c < NC; c++)
+    if (c < chunks) cnt += __popcll(__ballot(d[c] < trial));
+  return cnt;
+}
+template <int NC>
+__device__ __forceinline__ unsigned kth_smallest_bits(const unsigned (&d)[NC], const int chunks, const int k, bool& lt_only, const unsigned upper = 0u) {
+  unsigned V = 0;
+  int bit = 30;
+  lt_only = false;
+  if (upper >= (4u << 23) && upper < 0x7F800000u) {
+    const unsigned e = upper >> 23;   // the k-th smallest is below (e + 1) << 23
+#pragma unroll 1
+    for (unsigned t = 0; t < 3u; t++) {
+      const unsigned base = (e - t) << 23;
+      const int cnt = count_below<NC>(d, chunks, base);
+      if (cnt == k) { lt_only = true; return base; }
+      if (cnt < k) { V = base; bit = 22; break; }   // fewer than k below this binade, at least k below the next: the answer has this exponent
+    }
+  }
+#pragma unroll 1
+  for (; bit >= 0; bit--) {
+    const unsigned trial = V | (1u << bit);
+    const int cnt = count_below<NC>(d, chunks, trial);
     if (cnt == k) { lt_only = true; return trial; }
     if (cnt < k) V = trial;
   }
   return V;
 }
 
-// step (b): the leaves within Tl[j] * scale of any query j of `open`; returns their number, or -1 when a list overflowed
+// An UPPER BOUND of the k-th smallest of the wave's values: the descent above cut after the top `rounds` bits, the undecided low bits
+// set (so that at least k values are <= the result).  For the window bound of step (a), which only prunes.
+__device__ __forceinline__ unsigned kth_smallest_upper_bound(const unsigned d, const int k, const int rounds) {
+  unsigned V = 0;
+  int bit = 30;
+#pragma unroll 1
+  for (; bit > 30 - rounds; bit--) {
+    const unsigned trial = V | (1u << bit);
+    const int cnt = __popcll(__ballot(d < trial));
+    if (cnt == k) return trial;        // exactly k values below trial: the k-th smallest is below it
+    if (cnt < k) V = trial;
+  }
+  return V | ((2u << bit) - 1u);        // the k-th smallest has prefix V: it is at most V with every lower bit set
+}
+
+// Step (a) for NQ queries j0 .. j0 + NQ - 1 of the leaf at once: per query an UPPER BOUND of the k-th smallest distance to the 64 window
+// points (the top 14 bits of the bit descent, the undecided low bits set: within 1.6 %, and it only prunes), written to lane j of Tl.
+// Returns false when a query has fewer than k finite window points (the caller takes the careful path).
+template <int NQ>
+__device__ __forceinline__ bool knn_window_bounds(const float4 wp, const bool wfinite, const int w0, const int j0, const int k, float& Tl) {
+  const int lane = threadIdx.x & 63;
+  unsigned d[NQ], V[NQ];
+  bool done[NQ];
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < NQ; t++) {
+    const float qx = readlane_f32(wp.x, w0 + j0 + t), qy = readlane_f32(wp.y, w0 + j0 + t), qz = readlane_f32(wp.z, w0 + j0 + t);
+    const float dp = sqdist_rn(qx, qy, qz, wp.x, wp.y, wp.z);
+    d[t] = (wfinite && dp < INFINITY) ? __float_as_uint(dp) : kInfBits;
+    ok = ok && (__popcll(__ballot(d[t] < kInfBits)) >= k);
+    V[t] = 0;
+    done[t] = false;
+  }
+  if (!ok) return false;
+  constexpr int kRounds = 14;
+#pragma unroll 1
+  for (int bit = 30; bit > 30 - kRounds; bit--) {
+#pragma unroll
+    for (int t = 0; t < NQ; t++) {
+      const unsigned trial = V[t] | (1u << bit);
+      const int cnt = __popcll(__ballot(d[t] < trial));
+      if (!done[t]) {
+        if (cnt == k) { V[t] = trial; done[t] = true; }   // exactly k values below trial: the k-th smallest is below it
+        else if (cnt < k) V[t] = trial;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NQ; t++) {
+    const unsigned bound = done[t] ? V[t] : (V[t] | ((2u << (30 - kRounds)) - 1u));   // prefix V: at most V with every lower bit set
+    if (lane == j0 + t) Tl = __uint_as_float(bound);
+  }
+  return true;
+}
+
+// step (b): the leaves within Tl[j] * scale of any query j of `open`; returns their number, or -1 when a list overflowed.
+// Lane layout: 8 frontier nodes x 8 children per pass, the queries in a loop inside.  Measured and dropped (round 3, `profiles/r03`):
+// (query x child) lanes with one node per pass (no query loop, but 4-8x the passes: 0.174-0.190 against 0.168-0.173 ms per 65,536-point
+// cloud), and one test per node against the box of the open queries above the leaves (an eighth of the tests, but the sparse rings of a
+// 16-beam scan then overflow the frontier and walk again: 0.081 -> 0.160 ms per 26,668-point cloud).
 __device__ __forceinline__ int knn_gather_leaves(const BvhView& b, const float4 wp, const int w0, const int n_q, const unsigned open, const float Tl,
                                                  const float scale, int (*front)[kFrontCap], int* leaves) {
   const int lane = threadIdx.x & 63;
-  int cur = 0, count = 1;
-  if (lane == 0) front[0][0] = 0;
+  int cur = 0, count = 1, level0 = 0;
+  if (b.depth >= 3) {
+    // The 64 nodes two levels below the root (heap ids 9..72, their boxes at 8..71) in ONE pass, a node per lane: it replaces the
+    // three dependent passes root -> 8 -> 64 every wave would otherwise repeat.  Empty nodes carry inverted boxes and never hit.
+    const float4 lo = load16_at(b.box_lo, 8u + lane), hi = load16_at(b.box_hi, 8u + lane);
+    bool hit = false;
+#pragma unroll 1
+    for (int j = 0; j < n_q; j++) {
+      if (!((open >> j) & 1u)) continue;
+      const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
+      hit = hit || (aabb_sqdist_rn(lo, hi, qx, qy, qz) <= readlane_f32(Tl, j) * scale);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) front[0][lanes_below(m)] = 9 + lane;
+    count = __popcll(m);
+    level0 = 2;
+  } else if (lane == 0) {
+    front[0][0] = 0;
+  }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  for (int level = 0; level < b.depth; level++) {
+  for (int level = level0; level < b.depth; level++) {
     const bool last = level == b.depth - 1;
     int next = 0;
     for (int base = 0; base < count; base += 8) {
@@ -183,6 +282,91 @@ __device__ __forceinline__ int knn_gather_leaves(const BvhView& b, const float4 
   return count;
 }
 
+
+// step (c) for a candidate list of exactly NCH chunks (NCH * 8 leaves, the last chunk possibly partial): per open query the k-th smallest
+// candidate distance, the selection (ties at the k-th distance to the lower index) and its neighbour list; answered queries leave `open`
+template <int NCH>
+__device__ __forceinline__ void knn_select(const BvhView& b, const float4 wp, const int w0, const int n_q, const int n_cand, const int k, const float Tl,
+                                           const float scale, const int* leaves, int* __restrict__ nbr, const int l, unsigned& open) {
+  const int lane = threadIdx.x & 63;
+  float4 cp[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    cp[c] = make_float4(NAN, NAN, NAN, __uint_as_float(0xFFFFFFFFu));
+    {
+      const int li = c * 8 + (lane >> 3);
+      if (li < n_cand) cp[c] = load16_at(b.sorted, (unsigned)(leaves[li] * kLeaf + (lane & 7)));
+    }
+  }
+#pragma unroll 1
+  for (int j = 0; j < n_q; j++) {
+    if (!((open >> j) & 1u)) continue;
+    const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
+    const unsigned Ttry = __float_as_uint(readlane_f32(Tl, j) * scale);
+    unsigned d[NCH];
+    int within = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      d[c] = kInfBits;
+      {
+        const float dp = sqdist_rn(qx, qy, qz, cp[c].x, cp[c].y, cp[c].z);   // NaN for padding / empty lanes
+        if (dp < INFINITY && (int)__float_as_uint(cp[c].w) >= 0) d[c] = __float_as_uint(dp);
+        within += __popcll(__ballot(d[c] <= Ttry));
+      }
+    }
+    if (within < k) continue;   // the scaled bound was too small for this query: nothing can be concluded
+    bool lt;
+    const unsigned V = kth_smallest_bits<NCH>(d, NCH, k, lt, Ttry);   // at least k candidates are within Ttry: the answer is <= Ttry
+    // selection: everything below V; if V IS the k-th smallest, the k - (count below) lowest indices among the values equal to V
+    bool sel[NCH];
+    int below = 0, equal = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      sel[c] = d[c] < V;
+      { below += __popcll(__ballot(d[c] < V)); equal += __popcll(__ballot(d[c] == V)); }
+    }
+    if (!lt) {
+      const int need = k - below;
+      if (equal == need) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) sel[c] = d[c] <= V;
+      } else {
+        // more values at the k-th distance than places left: lowest index first (rare: duplicate or symmetric points)
+        for (int t = 0; t < need; t++) {
+          int mine = 0x7FFFFFFF;
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            if (d[c] == V && !sel[c]) mine = min(mine, (int)__float_as_uint(cp[c].w));
+          int best = mine;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            if (d[c] == V && (int)__float_as_uint(cp[c].w) == best) sel[c] = true;
+        }
+      }
+    }
+    int* __restrict__ out = nbr + (size_t)(l * kLeaf + j) * kKnnMax;
+    int written = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      {
+        const unsigned long long m = __ballot(sel[c]);
+        if (sel[c]) out[written + lanes_below(m)] = (int)__float_as_uint(cp[c].w);
+        written += __popcll(m);
+      }
+    }
+    open &= ~(1u << j);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void knn_select_dispatch(const int chunks, const BvhView& b, const float4 wp, const int w0, const int n_q, const int n_cand, const int k,
+                                                    const float Tl, const float scale, const int* leaves, int* __restrict__ nbr, const int l, unsigned& open) {
+  if (chunks <= N || N == kLeafChunks) knn_select<N>(b, wp, w0, n_q, n_cand, k, Tl, scale, leaves, nbr, l, open);
+  else if constexpr (N < kLeafChunks) knn_select_dispatch<N + 1>(chunks, b, wp, w0, n_q, n_cand, k, Tl, scale, leaves, nbr, l, open);
+}
+
 // `parts` (1, 2, 4 or 8) waves share a leaf, each answering 8 / parts of its queries: a small cloud has too few leaves to fill the
 // chip, and a wave's 8 selections are one dependent chain -- shorter chains on more waves, at the price of one walk per part.
 __global__ __launch_bounds__(kBlock) void gicp_knn_leaf_kernel(const BvhView b, const int n, const int k, const int parts, int* __restrict__ nbr, int* __restrict__ stats) {
@@ -205,102 +389,54 @@ __global__ __launch_bounds__(kBlock) void gicp_knn_leaf_kernel(const BvhView b, 
   const int n_q = min(kLeaf, n - l * kLeaf);                // queries of this leaf (the last leaf may be partial)
   const int per = kLeaf / parts, j_lo = part * per, j_hi = min(n_q, j_lo + per);
   if (j_lo >= j_hi) return;
+#ifdef DGS_KNN_STATS
+  const unsigned long long ts0 = wall_clock64();
+  unsigned long long acc_b = 0, acc_c = 0;
+#endif
   float Tl = 0.f;   // lane j holds T_j
   if (fast) {
-#pragma unroll 1
-    for (int j = j_lo; j < j_hi; j++) {
-      const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
-      const float dp = sqdist_rn(qx, qy, qz, wp.x, wp.y, wp.z);
-      unsigned d[1] = {(wfinite && dp < INFINITY) ? __float_as_uint(dp) : kInfBits};
-      if (__popcll(__ballot(d[0] < kInfBits)) < k) { fast = false; break; }
-      bool lt;
-      const unsigned V = kth_smallest_bits<1>(d, 1, k, lt);
-      if (lane == j) Tl = __uint_as_float(V);   // lt: the k-th smallest is below V; else it is V -- an upper bound either way
+    // the bounds of this wave's queries, their descents interleaved (one descent is a chain of dependent ballot -> count -> branch
+    // rounds; 2 / 4 / 8 of them side by side hide each other's latency)
+    switch (j_hi - j_lo) {
+      case 8: fast = knn_window_bounds<8>(wp, wfinite, w0, j_lo, k, Tl); break;
+      case 4: fast = knn_window_bounds<4>(wp, wfinite, w0, j_lo, k, Tl); break;
+      case 2: fast = knn_window_bounds<2>(wp, wfinite, w0, j_lo, k, Tl); break;
+      default:
+        for (int j = j_lo; j < j_hi && fast; j++) fast = knn_window_bounds<1>(wp, wfinite, w0, j, k, Tl);
+        break;
     }
   }
+#ifdef DGS_KNN_STATS
+  const unsigned long long ts1 = wall_clock64();
+#endif
   unsigned open = ((1u << j_hi) - 1u) & ~((1u << j_lo) - 1u);
   int iters = 0;
   if (fast) {
     float scale = 1.f, s_small = 0.f, s_over = 0.f;   // s_small: answered nobody new; s_over: overflowed (0 = not seen yet)
     for (; open != 0u && iters < kKnnRetries; iters++) {
+#ifdef DGS_KNN_STATS
+      const unsigned long long tb0 = wall_clock64();
+#endif
       const int n_cand = knn_gather_leaves(b, wp, w0, n_q, open, Tl, scale, s_front[wv], s_leaves[wv]);
+#ifdef DGS_KNN_STATS
+      const unsigned long long tb1 = wall_clock64();
+      acc_b += tb1 - tb0;
+#endif
       if (n_cand < 0) {
         s_over = scale;
         scale = (s_small > 0.f) ? sqrtf(s_small * s_over) : scale * 0.0625f;
         continue;
       }
-      // ---- (c) candidates: chunk c = leaves c * 8 .. c * 8 + 7 of the list, lane -> (leaf lane / 8, point lane % 8)
+      // ---- (c) candidates: chunk c = leaves c * 8 .. c * 8 + 7 of the list, lane -> (leaf lane / 8, point lane % 8).  The chunk count
+      // is a template argument: with it as a run-time bound every one of the dozen per-chunk loops below carried a scalar compare and a
+      // branch per possible chunk and round -- the kernel was bound by the CU's one scalar unit (2,600 scalar against 1,360 vector
+      // instructions per wave, `profiles/r03/knn_*`), not by anything it computes.
       const int chunks = (n_cand + 7) >> 3;
-      float4 cp[kLeafChunks];
-#pragma unroll
-      for (int c = 0; c < kLeafChunks; c++) {
-        cp[c] = make_float4(NAN, NAN, NAN, __uint_as_float(0xFFFFFFFFu));
-        if (c < chunks) {
-          const int li = c * 8 + (lane >> 3);
-          if (li < n_cand) cp[c] = load16_at(b.sorted, (unsigned)(s_leaves[wv][li] * kLeaf + (lane & 7)));
-        }
-      }
       const unsigned was_open = open;
-#pragma unroll 1
-      for (int j = 0; j < n_q; j++) {
-        if (!((open >> j) & 1u)) continue;
-        const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
-        const unsigned Ttry = __float_as_uint(readlane_f32(Tl, j) * scale);
-        unsigned d[kLeafChunks];
-        int within = 0;
-#pragma unroll
-        for (int c = 0; c < kLeafChunks; c++) {
-          d[c] = kInfBits;
-          if (c < chunks) {
-            const float dp = sqdist_rn(qx, qy, qz, cp[c].x, cp[c].y, cp[c].z);   // NaN for padding / empty lanes
-            if (dp < INFINITY && (int)__float_as_uint(cp[c].w) >= 0) d[c] = __float_as_uint(dp);
-            within += __popcll(__ballot(d[c] <= Ttry));
-          }
-        }
-        if (within < k) continue;   // the scaled bound was too small for this query: nothing can be concluded
-        bool lt;
-        const unsigned V = kth_smallest_bits<kLeafChunks>(d, chunks, k, lt);
-        // selection: everything below V; if V IS the k-th smallest, the k - (count below) lowest indices among the values equal to V
-        bool sel[kLeafChunks];
-        int below = 0, equal = 0;
-#pragma unroll
-        for (int c = 0; c < kLeafChunks; c++) {
-          sel[c] = c < chunks && d[c] < V;
-          if (c < chunks) { below += __popcll(__ballot(d[c] < V)); equal += __popcll(__ballot(d[c] == V)); }
-        }
-        if (!lt) {
-          const int need = k - below;
-          if (equal == need) {
-#pragma unroll
-            for (int c = 0; c < kLeafChunks; c++) sel[c] = c < chunks && d[c] <= V;
-          } else {
-            // more values at the k-th distance than places left: lowest index first (rare: duplicate or symmetric points)
-            for (int t = 0; t < need; t++) {
-              int mine = 0x7FFFFFFF;
-#pragma unroll
-              for (int c = 0; c < kLeafChunks; c++)
-                if (c < chunks && d[c] == V && !sel[c]) mine = min(mine, (int)__float_as_uint(cp[c].w));
-              int best = mine;
-#pragma unroll
-              for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o));
-#pragma unroll
-              for (int c = 0; c < kLeafChunks; c++)
-                if (c < chunks && d[c] == V && (int)__float_as_uint(cp[c].w) == best) sel[c] = true;
-            }
-          }
-        }
-        int* __restrict__ out = nbr + (size_t)(l * kLeaf + j) * kKnnMax;
-        int written = 0;
-#pragma unroll
-        for (int c = 0; c < kLeafChunks; c++) {
-          if (c < chunks) {
-            const unsigned long long m = __ballot(sel[c]);
-            if (sel[c]) out[written + lanes_below(m)] = (int)__float_as_uint(cp[c].w);
-            written += __popcll(m);
-          }
-        }
-        open &= ~(1u << j);
-      }
+      knn_select_dispatch<1>(chunks, b, wp, w0, n_q, n_cand, k, Tl, scale, s_leaves[wv], nbr, l, open);
+#ifdef DGS_KNN_STATS
+      acc_c += wall_clock64() - tb1;
+#endif
       if (open != 0u) {
         if (open != was_open) s_over = 0.f;   // fewer queries now: what overflowed before may fit
         s_small = scale;
@@ -309,7 +445,10 @@ __global__ __launch_bounds__(kBlock) void gicp_knn_leaf_kernel(const BvhView b, 
     }
   }
 #ifdef DGS_KNN_STATS
-  if (lane == 0) { atomicAdd(&stats[0], 1); atomicAdd(&stats[1], (fast && open == 0u) ? 1 : 0); atomicAdd(&stats[2], iters); atomicAdd(&stats[3], iters > 1 ? 1 : 0); }
+  if (lane == 0) {
+    atomicAdd(&stats[0], 1); atomicAdd(&stats[1], (fast && open == 0u) ? 1 : 0); atomicAdd(&stats[2], iters); atomicAdd(&stats[3], iters > 1 ? 1 : 0);
+    atomicAdd(&stats[4], (int)(ts1 - ts0)); atomicAdd(&stats[5], (int)acc_b); atomicAdd(&stats[6], (int)acc_c); atomicAdd(&stats[7], (int)(wall_clock64() - ts0));
+  }
 #endif
   if (fast && open == 0u) return;
   // ---- the careful path: the per-query walk, 8 lanes per query
@@ -331,44 +470,63 @@ __global__ __launch_bounds__(kBlock) void gicp_knn_leaf_kernel(const BvhView b, 
   }
 }
 
+// One wave per 64 points, two phases.  (1) eight rounds of 8 points, 8 lanes per point: gather the neighbours, mean and covariance in
+// double, reduced inside the 8-lane group; the six covariance entries of every point go to LDS.  (2) lane t regularises point t.
+// (Regularising in phase 1's layout left 56 of 64 lanes idle through the 3x3 decomposition, which is most of this kernel's
+// instructions: 1,964 VALU instructions per wave of 8 points.)  Same arithmetic per point as before, bit for bit.
 __global__ __launch_bounds__(kBlock) void gicp_cov_from_knn_kernel(const BvhView b, const float4* __restrict__ pts, const int n, const int k, const int method,
                                                                    const int* __restrict__ nbr, double* __restrict__ cov6) {
-  const int sub = threadIdx.x & 7;
-  const int pos = (blockIdx.x * kBlock + threadIdx.x) >> 3;
-  if (pos >= n) return;
-  const int i = (int)__float_as_uint(b.sorted[pos].w);
-  if (i < 0 || i >= n) return;
-  // neighbours of this lane (slots r * 8 + sub < k); slots that found nothing are zero columns, as upstream's matrix
-  double px[kKnnSlots], py[kKnnSlots], pz[kKnnSlots];
-  bool use[kKnnSlots];
-  double sx = 0, sy = 0, sz = 0;
-#pragma unroll
-  for (int r = 0; r < kKnnSlots; r++) {
-    use[r] = (r * 8 + sub) < k;
-    const int j = use[r] ? nbr[(size_t)pos * kKnnMax + r * 8 + sub] : -1;
-    const float4 p = (j >= 0) ? pts[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    px[r] = p.x; py[r] = p.y; pz[r] = p.z;
-    if (use[r]) { sx += px[r]; sy += py[r]; sz += pz[r]; }
-  }
+  __shared__ double s_c[kBlock / kWave][kWave][6];
+  __shared__ int s_i[kBlock / kWave][kWave];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 7, grp = lane >> 3;
+  const int wave_base = (blockIdx.x * (kBlock / kWave) + wv) * kWave;   // first point (position in index order) of this wave
+  if (wave_base >= n) return;
   const double kk = (double)k;
-  const double mx = group8_sum_f64(sx) / kk, my = group8_sum_f64(sy) / kk, mz = group8_sum_f64(sz) / kk;
-  double c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+  for (int r = 0; r < 8; r++) {
+    const int pos = wave_base + r * 8 + grp;
+    int i = -1;
+    if (pos < n) i = (int)__float_as_uint(b.sorted[pos].w);
+    const bool live = i >= 0 && i < n;
+    // neighbours of this lane (slots q * 8 + sub < k); slots that found nothing are zero columns, as upstream's matrix
+    double px[kKnnSlots], py[kKnnSlots], pz[kKnnSlots];
+    bool use[kKnnSlots];
+    double sx = 0, sy = 0, sz = 0;
 #pragma unroll
-  for (int r = 0; r < kKnnSlots; r++) {
-    if (use[r]) {
-      const double dx = px[r] - mx, dy = py[r] - my, dz = pz[r] - mz;
-      c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+    for (int q = 0; q < kKnnSlots; q++) {
+      use[q] = (q * 8 + sub) < k;
+      const int j = (live && use[q]) ? nbr[(size_t)pos * kKnnMax + q * 8 + sub] : -1;
+      const float4 p = (j >= 0) ? pts[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      px[q] = p.x; py[q] = p.y; pz[q] = p.z;
+      if (use[q]) { sx += px[q]; sy += py[q]; sz += pz[q]; }
+    }
+    const double mx = group8_sum_f64(sx) / kk, my = group8_sum_f64(sy) / kk, mz = group8_sum_f64(sz) / kk;
+    double c[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < kKnnSlots; q++) {
+      if (use[q]) {
+        const double dx = px[q] - mx, dy = py[q] - my, dz = pz[q] - mz;
+        c[0] += dx * dx; c[1] += dx * dy; c[2] += dx * dz; c[3] += dy * dy; c[4] += dy * dz; c[5] += dz * dz;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) c[a] = group8_sum_f64(c[a]) / kk;
+    if (sub == 0) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) s_c[wv][r * 8 + grp][a] = c[a];
+      s_i[wv][r * 8 + grp] = live ? i : -1;
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS stores have landed
+  const int i = s_i[wv][lane];
+  if (i < 0) return;
+  const double* c = s_c[wv][lane];
+  const double cov9[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+  double out6[6];
+  regularize_cov(cov9, method, out6);
 #pragma unroll
-  for (int a = 0; a < 6; a++) c[a] = group8_sum_f64(c[a]) / kk;
-  if (sub == 0) {
-    const double cov9[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
-    double out6[6];
-    regularize_cov(cov9, method, out6);
-#pragma unroll
-    for (int a = 0; a < 6; a++) cov6[(size_t)i * 6 + a] = out6[a];
-  }
+  for (int a = 0; a < 6; a++) cov6[(size_t)i * 6 + a] = out6[a];
 }
 
 // ================================================================================================ K5 correspondences
@@ -936,7 +1094,7 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
   DGS_HIP_TRY(h, c.cov.reserve((size_t)c.n * 6));
   const BvhView v = make_bvh_view(c.bvh);
   DGS_HIP_TRY(h, h->knn_nbr.reserve((size_t)c.n * kKnnMax));
-  DGS_HIP_TRY(h, h->knn_stats.reserve(4));
+  DGS_HIP_TRY(h, h->knn_stats.reserve(8));
   // rounds per wave: enough waves to fill the chip several times over, and stretches long enough for the warm bounds to pay
   const int run = (int)std::max<int64_t>(1, std::min<int64_t>(h->knn_rounds, (c.n + 8 * (int64_t)h->knn_min_waves - 1) / (8 * (int64_t)h->knn_min_waves)));
   const int64_t waves = (c.n + 8 * (int64_t)run - 1) / (8 * (int64_t)run);
@@ -948,7 +1106,7 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
     while (parts < 4 && n_leaves * parts < 16384) parts *= 2;
     if (h->knn_parts > 0) parts = h->knn_parts;
 #ifdef DGS_KNN_STATS
-    (void)hipMemsetAsync(h->knn_stats.ptr, 0, 4 * sizeof(int), h->stream);
+    (void)hipMemsetAsync(h->knn_stats.ptr, 0, 8 * sizeof(int), h->stream);
 #endif
     hipLaunchKernelGGL(gicp_knn_leaf_kernel, dim3((unsigned)((n_leaves * parts + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, h->stream, v, (int)c.n,
                        h->gconsts.k, parts, h->knn_nbr.ptr, h->knn_stats.ptr);
@@ -956,17 +1114,19 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
     hipLaunchKernelGGL(gicp_knn_kernel, dim3((unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, h->stream, v, (int)c.n, h->gconsts.k, run,
                        h->knn_nbr.ptr);
   }
-  hipLaunchKernelGGL(gicp_cov_from_knn_kernel, dim3((unsigned)(((int64_t)c.n * 8 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
+  hipLaunchKernelGGL(gicp_cov_from_knn_kernel, dim3((unsigned)(((int64_t)c.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
                      h->gconsts.k, h->gconsts.regularization, h->knn_nbr.ptr, c.cov.ptr);
   prof_end(h, DGS_K_GICP_COVARIANCE, slot);
   DGS_HIP_TRY(h, hipGetLastError());
 #ifdef DGS_KNN_STATS
   if (h->knn_leaf) {
-    int st[4];
+    int st[8];
     (void)hipMemcpyAsync(st, h->knn_stats.ptr, sizeof(st), hipMemcpyDeviceToHost, h->stream);
     (void)hipStreamSynchronize(h->stream);
-    fprintf(stderr, "[knn] n %lld waves %d answered cooperatively %d (%.2f %%) gather rounds per wave %.3f waves that retried %d\n", (long long)c.n, st[0], st[1],
-            100.0 * st[1] / std::max(st[0], 1), (double)st[2] / std::max(st[0], 1), st[3]);
+    const double w = std::max(st[0], 1);
+    fprintf(stderr, "[knn] n %lld waves %d answered cooperatively %d (%.2f %%) gather rounds per wave %.3f waves that retried %d; per wave (us): window bounds %.2f, "
+            "leaf walk %.2f, selection %.2f, whole %.2f\n", (long long)c.n, st[0], st[1], 100.0 * st[1] / w, (double)st[2] / w, st[3], st[4] * 0.01 / w, st[5] * 0.01 / w,
+            st[6] * 0.01 / w, st[7] * 0.01 / w);
   }
 #endif
   c.cov_valid = true;
