@@ -301,6 +301,10 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (const char* e = std::getenv("DGS_NDT_QUEUE")) h->ndt_queue_mode = std::atoi(e);
   if (const char* e = std::getenv("DGS_NDT_SCHEDULE")) h->ndt_schedule = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NDT_QUEUE_MIN_PAIRS")) h->ndt_queue_min_pairs = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("DGS_EARLY_FITNESS")) h->early_fitness_enabled = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_EARLY_FITNESS_LDS_KB")) h->early_fit.lds_kb = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("DGS_EARLY_FITNESS_MAX_ACTIVE")) h->early_fit.max_active = std::max(0, std::atoi(e));
+  if (const char* e = std::getenv("DGS_EARLY_FITNESS_MIN_PAIRS")) h->early_fit.min_pairs = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DGS_NN_KD")) h->nn_kd = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD_ALL")) h->nn_kd_all = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NN_KD_MIN_QUERIES")) h->nn_kd_min_queries = std::atoll(e);
@@ -347,6 +351,7 @@ void dgs_destroy(dgs_handle* h) {
   for (auto& ep : h->prof.pool) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->done_flags) (void)hipHostFree(h->done_flags);
+  if (h->fit_host) (void)hipHostFree(h->fit_host);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -706,14 +711,26 @@ int dgs_align_batch(dgs_handle* h, int32_t n, const float* const* sources, const
     if (rs != DGS_OK) return rs;
     h->side_build_deferred = true;
   }
+  int max_n = 0;
+  for (int i = 0; i < n; i++) max_n = std::max(max_n, sz[i]);
+  // the walk of a finished candidate starts while the others still iterate (ndt_align_pairs); kernels timed one by one stay in line
+  h->early_fit.on = h->early_fitness_enabled && compute_fitness && !h->prof.enabled && !h->use_grid && n <= 65535;
+  h->early_fit.enqueued = false;
+  h->early_fit.max_range = fitness_max_range;
+  h->early_fit.max_n = max_n;
   int rc = ndt_align_pairs(h, n, ptrs.data(), sz.data(), guesses16, results);
+  h->early_fit.on = false;
   if (side_join(h) != DGS_OK && rc == DGS_OK) rc = DGS_ERR_HIP;  // whatever happened above, nothing stays pending
-  if (rc == DGS_OK && compute_fitness) {
+  if (rc == DGS_OK && compute_fitness && h->early_fit.enqueued) {
+    // walked and totalled inside ndt_align_pairs, whose export synchronised the stream
+    std::vector<double> sums(n);
+    std::vector<int64_t> cnts(n), inl(n);
+    nn_fitness_read(h, n, sums.data(), cnts.data(), inl.data());
+    for (int i = 0; i < n; i++) results[i].fitness = cnts[i] > 0 ? sums[i] / (double)cnts[i] : DBL_MAX;
+  } else if (rc == DGS_OK && compute_fitness) {
     // getFitnessScore for every candidate in one launch; transforms are read from the optimiser state in HBM
     std::vector<double> sums(n);
     std::vector<int64_t> cnts(n), inl(n);
-    int max_n = 0;
-    for (int i = 0; i < n; i++) max_n = std::max(max_n, sz[i]);
     const float* dT = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->pairs.ptr) + offsetof(NdtPair, final_T));
     rc = nn_fitness_batch(h, n, h->src_ptrs.ptr, h->src_sizes.ptr, max_n, dT, sizeof(NdtPair), fitness_max_range, 0.0, sums.data(), cnts.data(),
                           inl.data());

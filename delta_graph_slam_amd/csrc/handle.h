@@ -185,6 +185,26 @@ struct dgs_handle {
   bool have_result = false;
 
   dgs::DevBuf<double> nn_partials;
+  int nn_bpp = 0;                   // rows (workgroups) per pair of the fitness batch being prepared / walked
+  double* fit_host = nullptr;       // pinned: the totals of the last fitness batch ({sum, count, inliers, 0} per pair)
+  int fit_host_cap = 0;
+  // dgs_align_batch -> ndt_align_pairs: walk the fitness of the candidates that have finished on the side stream while the rest iterate
+  struct EarlyFitness {
+    bool on = false;        // wanted for the batch being aligned
+    bool enqueued = false;  // ndt_align_pairs has enqueued every pair's walk, the totals and their copy: read fit_host after its sync
+    double max_range = 0.0;
+    int max_n = 0;
+    int lds_kb = 0;         // DGS_EARLY_FITNESS_LDS_KB: occupancy cap of the side-stream walks (workgroups per CU = 160 / this; 0 = none)
+    int max_active = 1 << 30;   // DGS_EARLY_FITNESS_MAX_ACTIVE: side-stream walks start once at most this many pairs still iterate
+    int min_pairs = 8;      // DGS_EARLY_FITNESS_MIN_PAIRS: a side-stream launch waits until this many finished pairs are ready
+  } early_fit;
+  // DGS_EARLY_FITNESS=1.  Off by default: measured on the bench workload (scripts/ab_early_fitness.sh, profiles/r03/early_fitness_ab.txt)
+  // it never beat the plain order -- 2.19-2.22 ms per step against 2.15 at best (8+ pairs per launch, no occupancy cap), 2.4-3.3 ms with
+  // the cap, 4.3 ms with a launch per finished pair.  A walk's workgroup lives ~100 us whatever the launch holds, so (i) a launch per
+  // few pairs leaves the chip as empty as the tail it was meant to fill, (ii) a large launch floods every slot and the iteration
+  // launch that arrives next waits one workgroup lifetime (35 -> 90-120 us in the trace), (iii) capped to 1-2 workgroups per CU the
+  // walk is several times slower and the end of the batch waits for it.
+  bool early_fitness_enabled = false;
   const double* nn_out = nullptr;   // device: {sum, count, inliers, 0} per pair of the last fitness batch (inside nn_partials; read by dgs_group's record kernel)
   dgs::DevBuf<float4> scratch_cloud;
   dgs::NnGrid tgt_grid, aux_grid;   // fitness-pass index over the current target / over cloud1 of dgs_calc_fitness_score
@@ -250,6 +270,12 @@ int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs
                      size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
 int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
                         const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers);
+int nn_fitness_prepare(dgs_handle* h, int n_pairs, int max_size, bool grid);
+// ids: `count` pair indices (< 65,536) to walk, or nullptr for pairs 0 .. count - 1
+void nn_fitness_enqueue(dgs_handle* h, hipStream_t st, const Bvh& index, const int* ids, int count, const float4* const* d_src_ptrs, const int* d_sizes,
+                        const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, int background_lds_kb);
+int nn_fitness_totals_enqueue(dgs_handle* h, int n_pairs);
+void nn_fitness_read(const dgs_handle* h, int n_pairs, double* sums, int64_t* counts, int64_t* inliers);
 int nn_search(dgs_handle* h, const float4* queries, int64_t m, int32_t* d_idx, float* d_sq);
 int ensure_target_index(dgs_handle* h, hipStream_t st = nullptr);   // tree (+ grid when h->use_grid) over the current target
 // the grid pass pays for its build (one more sort of the target) from ~4 x 65,536 queries on: fitness of a candidate batch

@@ -1051,7 +1051,7 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
 // QUEUE: called inside the persistent queue kernel -- the pair's record was written by another workgroup of the SAME launch and will be
 // read by others: coherent (agent-scope) loads and write-through stores for every word of it.  Returns (to the closing wave) whether
 // the registration has ended.
-// DONE_FLAG: `done_counter` is this pair's own flag in HOST memory (pinned, device-visible): a finished pair stores 1 into it and the host
+// DONE_FLAG: `done_counter` is this pair's own flag in HOST memory (pinned, device-visible): a finished pair stores launch + 1 into it and the host
 // counts the flags at every chunk boundary -- no copy command between the chunks of launches (each cost the stream ~8 us: a blit kernel
 // and two barriers).  Otherwise a device counter that the host copies back.
 template <bool QUEUE, bool DONE_FLAG>
@@ -1133,7 +1133,7 @@ __device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* 
   if (writer && s.phase == PH_DONE) {
     st->active = 0;
     if (launch >= 0) st->last_launch = launch;
-    if (DONE_FLAG) __hip_atomic_store(done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (DONE_FLAG) __hip_atomic_store(done_counter, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // which launch ended it (ndt_align_pairs: early fitness)
     else atomicAdd(done_counter, 1);
   }
   CLOSE_STAMP(4)
@@ -1758,6 +1758,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
     return DGS_OK;
   }
 
+  if (h->early_fit.on && (rc = nn_fitness_prepare(h, n_pairs, h->early_fit.max_n, false)) != DGS_OK) return rc;
   // ---- iterate: chunks of (derivatives, solve) launches; the host looks at the done counter one chunk behind
   volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);  // [0], [1]: done counts of alternating chunks
   flags[0] = flags[1] = 0;
@@ -1786,6 +1787,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   NdtLaunch Lq = L;
   if (schedule) choose_queue(h, Lq);
   int round_no = 0;
+  int launches_upto[2] = {0, 0};   // launches enqueued up to the end of the chunk of either slot
   auto enqueue_chunk = [&](int slot, int launches) -> int {
     for (int e = 0; e < launches; e++) {
       NdtLaunch Lr = L;
@@ -1802,6 +1804,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
       }
     }
     queued += launches;
+    launches_upto[slot] = launch_no;
     if (!fused_flags) DGS_HIP_TRY(h, hipMemcpyAsync(const_cast<int*>(&flags[slot]), h->done_counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
     DGS_HIP_TRY(h, hipEventRecord(ev[slot], st));
     return DGS_OK;
@@ -1809,8 +1812,35 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   auto pairs_done = [&](int slot) -> int {
     if (!fused_flags) return flags[slot];
     int n = 0;
-    for (int i = 0; i < n_pairs; i++) n += reinterpret_cast<volatile int*>(h->done_flags)[i];
+    for (int i = 0; i < n_pairs; i++) n += reinterpret_cast<volatile int*>(h->done_flags)[i] != 0;
     return n;
+  };
+  // ---- early fitness (dgs_align_batch, compute_fitness): the nearest-neighbour walk of a candidate needs only its final transform, and
+  // the tail of a batch -- a few pairs still iterating, 11 us of latency per launch -- leaves most of the chip idle.  At every chunk
+  // boundary the pairs whose closing launch is KNOWN to have completed (flag = launch + 1 <= the launches the synchronised event covers:
+  // their state is in memory, not in some XCD's L2) get their walk on the low-priority side stream, behind the target's index build.
+  // Whatever is left at the end goes on the main stream.  A pair's rows and their order do not depend on which launch walked it.
+  const bool early = h->early_fit.on && fused_flags;
+  std::vector<char> walked(early ? n_pairs : 0, 0);
+  const float* fit_T = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h->pairs.ptr) + offsetof(NdtPair, final_T));
+  std::vector<int> ready;
+  auto walk_finished = [&](int completed, bool rest) -> int {
+    ready.clear();
+    for (int i = 0; i < n_pairs; i++) {
+      if (walked[i]) continue;
+      const int f = reinterpret_cast<volatile int*>(h->done_flags)[i];
+      if (rest || (f != 0 && f <= completed)) ready.push_back(i);
+    }
+    // a walk's workgroups live ~100 us whatever the number of pairs: few large launches, not one per finished pair
+    if (ready.empty() || (!rest && ((int)ready.size() < h->early_fit.min_pairs || n_pairs - pairs_done(0) > h->early_fit.max_active))) return DGS_OK;
+    for (int i : ready) walked[i] = 1;
+    nn_fitness_enqueue(h, rest ? st : h->side_stream, h->tgt->bvh, ready.data(), (int)ready.size(), h->src_ptrs.ptr, h->src_sizes.ptr, fit_T, sizeof(NdtPair),
+                       h->early_fit.max_range, 0.0, rest ? 0 : h->early_fit.lds_kb);
+    if (!rest) {
+      DGS_HIP_TRY(h, hipEventRecord(h->ev_join, h->side_stream));
+      h->side_pending = true;
+    }
+    return DGS_OK;
   };
   int cur = 0;
   // with a build waiting for the side stream the first chunk is twice as long: the host needs ~0.1 ms to enqueue that build, and
@@ -1829,12 +1859,21 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
     first = false;
     hipError_t e = hipEventSynchronize(ev[cur]);
     if (e != hipSuccess) { h->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; break; }
+    if (early && (rc = walk_finished(launches_upto[cur], false)) != DGS_OK) break;
     if (pairs_done(cur) >= n_pairs) { finished = true; break; }
     if (!more) break;
     cur ^= 1;
   }
   if (rc != DGS_OK) return rc;
   (void)finished;  // pairs that did not finish inside max_evals export converged = 0
+  if (early) {
+    // the main stream waits for the side stream (index build, early walks), walks the rest, totals everything and copies it out: the
+    // export's synchronisation below covers all of it
+    if (side_join(h) != DGS_OK) return DGS_ERR_HIP;
+    if ((rc = walk_finished(0, true)) != DGS_OK) return rc;
+    if ((rc = nn_fitness_totals_enqueue(h, n_pairs)) != DGS_OK) return rc;
+    h->early_fit.enqueued = true;
+  }
   return ndt_export(h, n_pairs, results);
 }
 

@@ -342,11 +342,17 @@ __global__ __launch_bounds__(kBlock) void nn_search_kernel(const BvhView b, cons
   }
 }
 
+// which pairs of a batch a fitness launch walks: blockIdx.y -> id[blockIdx.y]; n = 0: every pair, blockIdx.y itself
+struct NnPairList {
+  int n;
+  unsigned short id[62];
+};
+
 // fitness / inlier accumulation: per block one row {sum d2 (d2 <= max_range), count, inliers (d2 < inlier_sq)}
 __global__ __launch_bounds__(kBlock) void nn_fitness_kernel(const BvhView b, const float4* const* __restrict__ src_ptrs, const int* __restrict__ sizes,
                                                             const float* __restrict__ Tbase, size_t T_stride, float max_range, float inlier_sq,
-                                                            double* __restrict__ partial, int blocks_per_pair) {
-  const int pair = blockIdx.y;
+                                                            double* __restrict__ partial, int blocks_per_pair, const NnPairList list) {
+  const int pair = list.n ? (int)list.id[blockIdx.y] : (int)blockIdx.y;   // a chosen subset of the batch (early fitness), or all of it
   const float4* __restrict__ src = src_ptrs[pair];
   const int n = sizes[pair];
   const float* T = reinterpret_cast<const float*>(reinterpret_cast<const char*>(Tbase) + (size_t)pair * T_stride);  // column-major
@@ -544,39 +550,87 @@ int nn_fitness_batch(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs
                              inlier_sq, sums, counts, inliers);
 }
 
-int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
-                        const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
-  hipStream_t st = h->stream;
-  const BvhView v = make_bvh_view(index);
+// The fitness pass in three steps, so that dgs_align_batch can walk the candidates that have finished while the others still iterate
+// (ndt_align_pairs, `early_fit`): prepare (buffers, rows per pair -- a function of the WHOLE batch, so a pair's sum does not depend on
+// which launch walked it), enqueue (the walk of the listed pairs, or of all, on any stream), totals (per pair, and their copy to the host).
+int nn_fitness_prepare(dgs_handle* h, int n_pairs, int max_size, bool grid) {
   // tree walk: one query per 8 lanes; grid: one query per lane
   const int full = std::max(1, (int)(((int64_t)max_size * (grid ? 1 : 8) + kBlock - 1) / kBlock));
   static const int total_blocks = std::getenv("DGS_NN_BLOCKS") ? std::atoi(std::getenv("DGS_NN_BLOCKS")) : 8192;   // launch-shape sweeps
   const int bpp = std::max(1, std::min(full, std::max(64, total_blocks / std::max(1, n_pairs))));
   DGS_HIP_TRY(h, h->nn_partials.reserve((size_t)n_pairs * bpp * 4 + (size_t)n_pairs * 4));
-  double* d_out = h->nn_partials.ptr + (size_t)n_pairs * bpp * 4;
-  h->nn_out = d_out;
-  if (ensure_pinned(h, 4096 + sizeof(double) * 4 * n_pairs) != DGS_OK) return DGS_ERR_HIP;
+  h->nn_out = h->nn_partials.ptr + (size_t)n_pairs * bpp * 4;
+  h->nn_bpp = bpp;
+  if (h->fit_host_cap < n_pairs) {
+    if (h->fit_host) (void)hipHostFree(h->fit_host);
+    h->fit_host = nullptr;
+    h->fit_host_cap = 0;
+    DGS_HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->fit_host), sizeof(double) * 4 * (size_t)(n_pairs + 64), hipHostMallocDefault));
+    h->fit_host_cap = n_pairs + 64;
+  }
+  return DGS_OK;
+}
+
+void nn_fitness_enqueue(dgs_handle* h, hipStream_t st, const Bvh& index, const int* ids, int count, const float4* const* d_src_ptrs, const int* d_sizes,
+                        const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, int background_lds_kb) {
+  const BvhView v = make_bvh_view(index);
+  // background (beside the iteration launches of the same batch): a dynamic LDS request that nothing uses caps the walk at 160 / kb
+  // workgroups per CU, so that an iteration launch finds room at once -- a walk's workgroup lives ~100 us, several launches long
+  const unsigned lds = (unsigned)std::max(0, background_lds_kb) * 1024u;
   // PCL's comparison is float(sq_dist) <= double(max_range); clamp so DBL_MAX keeps every finite distance
   const float mr = (max_range >= (double)FLT_MAX) ? FLT_MAX : (float)max_range;
   const float iq = (inlier_sq >= (double)FLT_MAX) ? FLT_MAX : (float)inlier_sq;
+  NnPairList list{};
+  if (!ids) {   // pairs 0 .. count - 1
+    hipLaunchKernelGGL(nn_fitness_kernel, dim3(h->nn_bpp, count), dim3(kBlock), 0, st, v, d_src_ptrs, d_sizes, d_T, T_stride_bytes, mr, iq, h->nn_partials.ptr,
+                       h->nn_bpp, list);
+    return;
+  }
+  constexpr int kMax = (int)(sizeof(list.id) / sizeof(list.id[0]));
+  for (int o = 0; o < count; o += kMax) {
+    list.n = std::min(kMax, count - o);
+    for (int k = 0; k < list.n; k++) list.id[k] = (unsigned short)ids[o + k];
+    hipLaunchKernelGGL(nn_fitness_kernel, dim3(h->nn_bpp, list.n), dim3(kBlock), lds, st, v, d_src_ptrs, d_sizes, d_T, T_stride_bytes, mr, iq,
+                       h->nn_partials.ptr, h->nn_bpp, list);
+  }
+}
+
+// per-pair totals and the copy to the host, on the handle's stream; no synchronisation (nn_fitness_read after one)
+int nn_fitness_totals_enqueue(dgs_handle* h, int n_pairs) {
+  hipStream_t st = h->stream;
+  hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(n_pairs), dim3(kWave), 0, st, h->nn_partials.ptr, h->nn_bpp, n_pairs, const_cast<double*>(h->nn_out));
+  DGS_HIP_TRY(h, hipMemcpyAsync(h->fit_host, h->nn_out, sizeof(double) * 4 * n_pairs, hipMemcpyDeviceToHost, st));
+  return DGS_OK;
+}
+
+void nn_fitness_read(const dgs_handle* h, int n_pairs, double* sums, int64_t* counts, int64_t* inliers) {
+  for (int i = 0; i < n_pairs; i++) {
+    sums[i] = h->fit_host[i * 4 + 0];
+    counts[i] = (int64_t)h->fit_host[i * 4 + 1];
+    inliers[i] = (int64_t)h->fit_host[i * 4 + 2];
+  }
+}
+
+int nn_fitness_batch_on(dgs_handle* h, const Bvh& index, NnGrid* grid, int n_pairs, const float4* const* d_src_ptrs, const int* d_sizes, int max_size,
+                        const float* d_T, size_t T_stride_bytes, double max_range, double inlier_sq, double* sums, int64_t* counts, int64_t* inliers) {
+  hipStream_t st = h->stream;
+  int rc = nn_fitness_prepare(h, n_pairs, max_size, grid != nullptr);
+  if (rc) return rc;
   int slot = prof_begin(h, DGS_K_NN_SEARCH);
   if (grid) {
-    const int rg = nn_grid_launch_fitness(h, *grid, index, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, mr, iq, h->nn_partials.ptr, bpp);
+    const float mr = (max_range >= (double)FLT_MAX) ? FLT_MAX : (float)max_range;
+    const float iq = (inlier_sq >= (double)FLT_MAX) ? FLT_MAX : (float)inlier_sq;
+    const int rg = nn_grid_launch_fitness(h, *grid, index, n_pairs, d_src_ptrs, d_sizes, max_size, d_T, T_stride_bytes, mr, iq, h->nn_partials.ptr, h->nn_bpp);
     if (rg) return rg;
-  } else
-    hipLaunchKernelGGL(nn_fitness_kernel, dim3(bpp, n_pairs), dim3(kBlock), 0, st, v, d_src_ptrs, d_sizes, d_T, T_stride_bytes, mr, iq,
-                       h->nn_partials.ptr, bpp);
+  } else {
+    nn_fitness_enqueue(h, st, index, nullptr, n_pairs, d_src_ptrs, d_sizes, d_T, T_stride_bytes, max_range, inlier_sq, 0);
+  }
   prof_end(h, DGS_K_NN_SEARCH, slot);
-  hipLaunchKernelGGL(nn_fitness_final_kernel, dim3(n_pairs), dim3(kWave), 0, st, h->nn_partials.ptr, bpp, n_pairs, d_out);
-  double* hout = reinterpret_cast<double*>(reinterpret_cast<char*>(h->pinned) + 4096);
-  DGS_HIP_TRY(h, hipMemcpyAsync(hout, d_out, sizeof(double) * 4 * n_pairs, hipMemcpyDeviceToHost, st));
+  rc = nn_fitness_totals_enqueue(h, n_pairs);
+  if (rc) return rc;
   DGS_HIP_TRY(h, hipStreamSynchronize(st));
   DGS_HIP_TRY(h, hipGetLastError());
-  for (int i = 0; i < n_pairs; i++) {
-    sums[i] = hout[i * 4 + 0];
-    counts[i] = (int64_t)hout[i * 4 + 1];
-    inliers[i] = (int64_t)hout[i * 4 + 2];
-  }
+  nn_fitness_read(h, n_pairs, sums, counts, inliers);
   return DGS_OK;
 }
 
