@@ -232,9 +232,11 @@ __device__ __forceinline__ int knn_gather_leaves(const BvhView& b, const float4 
     // three dependent passes root -> 8 -> 64 every wave would otherwise repeat.  Empty nodes carry inverted boxes and never hit.
     const float4 lo = load16_at(b.box_lo, 8u + lane), hi = load16_at(b.box_hi, 8u + lane);
     bool hit = false;
+    // over the set bits of `open` (with 2 or 4 waves per leaf a wave has 4 or 2 of the 8 queries: a loop over all 8 spent most of its
+    // scalar instructions skipping the others)
 #pragma unroll 1
-    for (int j = 0; j < n_q; j++) {
-      if (!((open >> j) & 1u)) continue;
+    for (unsigned rest = open; rest != 0u; rest &= rest - 1u) {
+      const int j = __builtin_ctz(rest);
       const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
       hit = hit || (aabb_sqdist_rn(lo, hi, qx, qy, qz) <= readlane_f32(Tl, j) * scale);
     }
@@ -258,8 +260,8 @@ __device__ __forceinline__ int knn_gather_leaves(const BvhView& b, const float4 
       const float4 lo = load16_at(b.box_lo, ofs), hi = load16_at(b.box_hi, ofs);
       bool hit = false;
 #pragma unroll 1
-      for (int j = 0; j < n_q; j++) {
-        if (!((open >> j) & 1u)) continue;
+      for (unsigned rest = open; rest != 0u; rest &= rest - 1u) {
+        const int j = __builtin_ctz(rest);
         const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
         hit = hit || (aabb_sqdist_rn(lo, hi, qx, qy, qz) <= readlane_f32(Tl, j) * scale);
       }
@@ -299,8 +301,8 @@ __device__ __forceinline__ void knn_select(const BvhView& b, const float4 wp, co
     }
   }
 #pragma unroll 1
-  for (int j = 0; j < n_q; j++) {
-    if (!((open >> j) & 1u)) continue;
+  for (unsigned rest = open; rest != 0u; rest &= rest - 1u) {
+    const int j = __builtin_ctz(rest);
     const float qx = readlane_f32(wp.x, w0 + j), qy = readlane_f32(wp.y, w0 + j), qz = readlane_f32(wp.z, w0 + j);
     const unsigned Ttry = __float_as_uint(readlane_f32(Tl, j) * scale);
     unsigned d[NCH];
@@ -1101,9 +1103,10 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
   int slot = prof_begin(h, DGS_K_GICP_COVARIANCE);
   if (h->knn_leaf) {
     const int64_t n_leaves = (c.n + kLeaf - 1) / kLeaf;
-    // waves per leaf: measured best is 2 for a 65,536-point cloud (0.185 vs 0.199 ms), 4 for 26,700 points (0.119 vs 0.182 ms)
+    // waves per leaf (each answers 8 / parts of the leaf's queries after its own walk, whose loops run over ITS queries only): measured
+    // 1 / 2 / 4 / 8 waves per leaf: 0.168 / 0.148 / 0.143 / 0.160 ms per 65,536-point cloud, 0.099 / 0.076 / 0.065 / 0.069 ms per 26,668 points
     int parts = 1;
-    while (parts < 4 && n_leaves * parts < 16384) parts *= 2;
+    while (parts < 4 && n_leaves * parts < 32768) parts *= 2;
     if (h->knn_parts > 0) parts = h->knn_parts;
 #ifdef DGS_KNN_STATS
     (void)hipMemsetAsync(h->knn_stats.ptr, 0, 8 * sizeof(int), h->stream);
