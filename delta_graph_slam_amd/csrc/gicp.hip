@@ -476,16 +476,23 @@ __global__ __launch_bounds__(kBlock) void gicp_knn_leaf_kernel(const BvhView b, 
 // double, reduced inside the 8-lane group; the six covariance entries of every point go to LDS.  (2) lane t regularises point t.
 // (Regularising in phase 1's layout left 56 of 64 lanes idle through the 3x3 decomposition, which is most of this kernel's
 // instructions: 1,964 VALU instructions per wave of 8 points.)  Same arithmetic per point as before, bit for bit.
+#ifndef DGS_COV_ROUNDS
+#define DGS_COV_ROUNDS 4
+#endif
+// A wave takes kCovRounds * 8 points: rounds of 8 points (8 lanes each) for the sums, then one lane per point for the regularisation.
+// 8 rounds fill every lane of the second phase but leave a 65,536-point cloud with one wave per SIMD and nothing to hide its gathers
+// behind; measured 8 / 4 / 2 rounds: 23.6 / 20.8 / 25.4 us per 65,536-point cloud, 21.5 / 14.6 / 15.2 us per 26,668 points.
+constexpr int kCovRounds = DGS_COV_ROUNDS, kCovPerWave = kCovRounds * 8;
 __global__ __launch_bounds__(kBlock) void gicp_cov_from_knn_kernel(const BvhView b, const float4* __restrict__ pts, const int n, const int k, const int method,
                                                                    const int* __restrict__ nbr, double* __restrict__ cov6) {
-  __shared__ double s_c[kBlock / kWave][kWave][6];
-  __shared__ int s_i[kBlock / kWave][kWave];
+  __shared__ double s_c[kBlock / kWave][kCovPerWave][6];
+  __shared__ int s_i[kBlock / kWave][kCovPerWave];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = lane & 7, grp = lane >> 3;
-  const int wave_base = (blockIdx.x * (kBlock / kWave) + wv) * kWave;   // first point (position in index order) of this wave
+  const int wave_base = (blockIdx.x * (kBlock / kWave) + wv) * kCovPerWave;   // first point (position in index order) of this wave
   if (wave_base >= n) return;
   const double kk = (double)k;
 #pragma unroll 2
-  for (int r = 0; r < 8; r++) {
+  for (int r = 0; r < kCovRounds; r++) {
     const int pos = wave_base + r * 8 + grp;
     int i = -1;
     if (pos < n) i = (int)__float_as_uint(b.sorted[pos].w);
@@ -521,6 +528,7 @@ __global__ __launch_bounds__(kBlock) void gicp_cov_from_knn_kernel(const BvhView
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS stores have landed
+  if (lane >= kCovPerWave) return;
   const int i = s_i[wv][lane];
   if (i < 0) return;
   const double* c = s_c[wv][lane];
@@ -1117,7 +1125,8 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
     hipLaunchKernelGGL(gicp_knn_kernel, dim3((unsigned)((waves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, h->stream, v, (int)c.n, h->gconsts.k, run,
                        h->knn_nbr.ptr);
   }
-  hipLaunchKernelGGL(gicp_cov_from_knn_kernel, dim3((unsigned)(((int64_t)c.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
+  constexpr int kCovPerBlock = kCovPerWave * (kBlock / kWave);
+  hipLaunchKernelGGL(gicp_cov_from_knn_kernel, dim3((unsigned)(((int64_t)c.n + kCovPerBlock - 1) / kCovPerBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
                      h->gconsts.k, h->gconsts.regularization, h->knn_nbr.ptr, c.cov.ptr);
   prof_end(h, DGS_K_GICP_COVARIANCE, slot);
   DGS_HIP_TRY(h, hipGetLastError());
