@@ -317,8 +317,9 @@ __device__ __forceinline__ void knn_select(const BvhView& b, const float4 wp, co
       }
     }
     if (within < k) continue;   // the scaled bound was too small for this query: nothing can be concluded
-    bool lt;
-    const unsigned V = kth_smallest_bits<NCH>(d, NCH, k, lt, Ttry);   // at least k candidates are within Ttry: the answer is <= Ttry
+    bool lt = true;
+    // exactly k candidates within the bound (it sits at most 1.6 % above the k-th distance of the window): they are the answer, no descent
+    const unsigned V = (within == k) ? Ttry + 1u : kth_smallest_bits<NCH>(d, NCH, k, lt, Ttry);   // at least k are within Ttry: the answer is <= Ttry
     // selection: everything below V; if V IS the k-th smallest, the k - (count below) lowest indices among the values equal to V
     bool sel[NCH];
     int below = 0, equal = 0;
@@ -371,7 +372,10 @@ __device__ __forceinline__ void knn_select_dispatch(const int chunks, const BvhV
 
 // `parts` (1, 2, 4 or 8) waves share a leaf, each answering 8 / parts of its queries: a small cloud has too few leaves to fill the
 // chip, and a wave's 8 selections are one dependent chain -- shorter chains on more waves, at the price of one walk per part.
-__global__ __launch_bounds__(kBlock) void gicp_knn_leaf_kernel(const BvhView b, const int n, const int k, const int parts, int* __restrict__ nbr, int* __restrict__ stats) {
+#ifndef DGS_KNN_WAVES
+#define DGS_KNN_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock, DGS_KNN_WAVES) void gicp_knn_leaf_kernel(const BvhView b, const int n, const int k, const int parts, int* __restrict__ nbr, int* __restrict__ stats) {
   __shared__ int s_front[kBlock / kWave][2][kFrontCap];
   __shared__ int s_leaves[kBlock / kWave][kLeafCap];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
