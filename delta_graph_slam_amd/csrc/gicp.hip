@@ -372,6 +372,8 @@ __device__ __forceinline__ void knn_select_dispatch(const int chunks, const BvhV
 
 // `parts` (1, 2, 4 or 8) waves share a leaf, each answering 8 / parts of its queries: a small cloud has too few leaves to fill the
 // chip, and a wave's 8 selections are one dependent chain -- shorter chains on more waves, at the price of one walk per part.
+// -DDGS_KNN_WAVES: waves per SIMD the compiler must leave room for.  4 = what the kernel's 109 registers give anyway; 5 / 6 / 7 / 8 (with
+// -DDGS_KNN_LEAF_CAP = 64 / 48 / 40 / 32) were measured and are no faster, spills or not: the kernel is bound by the scalar unit.
 #ifndef DGS_KNN_WAVES
 #define DGS_KNN_WAVES 4
 #endif
