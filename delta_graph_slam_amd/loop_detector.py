@@ -77,6 +77,8 @@ class LoopDetector:
         self.cache_clouds = bool(cache_clouds)
         self.filter_on_device = bool(filter_on_device)   # find_candidates through dgs_find_loop_candidates (second half)
         self._cloud_cache = {}
+        self._exchange_buffers = {}
+        self.force_exchange = False   # measurement: run the exchange step even when the group has one rank (its floor: two copies + one collective)
 
     def resident(self, keyframe: "KeyFrame", as_target: bool = False):
         """KeyFrame::cloud as the registration should see it: the cached HBM-resident object when caching is on."""
@@ -175,21 +177,43 @@ class LoopDetector:
                     rec[j, 2] = r["fitness"]
                     rec[j, 3] = r.get("status", 0)
                     rec[j, 4:20] = np.asarray(r["T"], np.float64).reshape(16)
-        if world == 1:
+        if world == 1 and not self.force_exchange:
             allrec = rec
         else:
-            backend = dist.get_backend(self.group)
-            dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-            local = torch.from_numpy(rec).to(dev)
-            gathered = torch.empty((world * per_rank, RECORD_WIDTH), dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(gathered, local, group=self.group)   # the path's one exchange step
-            allrec = gathered.cpu().numpy()
+            allrec = self._exchange(rec, per_rank, world)
         out = np.full((n, RECORD_WIDTH), -1.0, dtype=np.float64)
         idx = allrec[:, 0].astype(np.int64)
         ok = (idx >= 0) & (idx < n)          # padding rows of the gather carry -1
         out[idx[ok]] = allrec[ok]
         self.last_records = out
         return out
+
+    def _exchange(self, rec: np.ndarray, per_rank: int, world: int) -> np.ndarray:
+        """The path's one exchange step: every rank's [per_rank, RECORD_WIDTH] records to every rank (ncclAllGather over RCCL, or gloo).
+        On the device path the staging buffers are made once per shape -- pinned host memory both ways, so that the two copies are
+        asynchronous and the step pays ONE synchronisation after the gather instead of a pageable copy either side of it."""
+        backend = dist.get_backend(self.group)
+        if backend != "nccl":
+            local = torch.from_numpy(rec)
+            gathered = torch.empty((world * per_rank, RECORD_WIDTH), dtype=torch.float64)
+            dist.all_gather_into_tensor(gathered, local, group=self.group)
+            return gathered.numpy()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        key = (per_rank, world, dev.index)
+        buf = self._exchange_buffers.get(key)
+        if buf is None:
+            buf = (torch.empty((per_rank, RECORD_WIDTH), dtype=torch.float64).pin_memory(),
+                   torch.empty((per_rank, RECORD_WIDTH), dtype=torch.float64, device=dev),
+                   torch.empty((world * per_rank, RECORD_WIDTH), dtype=torch.float64, device=dev),
+                   torch.empty((world * per_rank, RECORD_WIDTH), dtype=torch.float64).pin_memory())
+            self._exchange_buffers[key] = buf
+        host_in, dev_in, dev_out, host_out = buf
+        host_in.numpy()[...] = rec
+        dev_in.copy_(host_in, non_blocking=True)
+        dist.all_gather_into_tensor(dev_out, dev_in, group=self.group)
+        host_out.copy_(dev_out, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return host_out.numpy().copy()
 
     @staticmethod
     def select_best(records: np.ndarray):
