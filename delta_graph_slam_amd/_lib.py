@@ -37,6 +37,8 @@ class Params(C.Structure):
         ("gicp_lm_init_lambda_factor", C.c_double), ("gicp_correspondence_randomness", C.c_int32),
         ("gicp_regularization", C.c_int32), ("gicp_optimizer", C.c_int32), ("gicp_lm_max_iterations", C.c_int32),
         ("vgicp_search_method", C.c_int32), ("vgicp_resolution", C.c_double),
+        ("ndt_newton_solver", C.c_int32), ("ndt_hessian_recompute_double", C.c_int32), ("ndt_guess_rotation_polar", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -51,7 +53,7 @@ SYMBOLS = [
     "dgs_synchronize", "dgs_set_input_target", "dgs_set_input_source", "dgs_align", "dgs_get_fitness_score",
     "dgs_get_inlier_fraction", "dgs_nearest_search_target", "dgs_nn_fitness_distances", "dgs_align_batch", "dgs_find_loop_candidates", "dgs_calc_fitness_score", "dgs_voxel_grid_filter", "dgs_approx_voxel_grid_filter", "dgs_cloud_create", "dgs_cloud_destroy", "dgs_cloud_size",
     "dgs_set_input_target_cloud", "dgs_set_input_source_cloud", "dgs_align_batch_clouds", "dgs_profile_enable",
-    "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_get_voxels",
+    "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_hessian_double", "dgs_ndt_get_voxels",
     "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize", "dgs_vgicp_get_voxels",
     "dgs_group_create", "dgs_group_destroy", "dgs_group_last_error", "dgs_group_size", "dgs_group_uses_rccl", "dgs_group_last_gather_used_rccl",
     "dgs_group_member", "dgs_group_set_input_target", "dgs_group_align_batch",
@@ -110,6 +112,7 @@ def load(path=None):
     lib.dgs_profile_reset.argtypes = [C.c_void_p]
     lib.dgs_get_counts.argtypes = [C.c_void_p, P(C.c_int64)]
     lib.dgs_ndt_derivatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_double), C.c_void_p, C.c_void_p]
+    lib.dgs_ndt_hessian_double.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dgs_ndt_get_voxels.argtypes = [C.c_void_p, P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dgs_ndt_get_trajectory.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, P(C.c_int32)]
     lib.dgs_gicp_get_covariances.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]

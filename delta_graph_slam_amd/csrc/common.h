@@ -28,6 +28,17 @@ struct __attribute__((aligned(16))) VoxelRec {
 };
 static_assert(sizeof(VoxelRec) == 48, "VoxelRec must be 48 bytes");
 
+// The same voxel as the UPSTREAM evaluation orders read it (ndt_strict_order >= 1): all nine entries of the inverse covariance
+// as upstream casts them to float (after the eigenvalue clamp the matrix is rebuilt as V diag V^-1 and is not exactly symmetric).
+// 64 bytes, four aligned 16-byte loads.  (The double inverse covariance of the double-precision computeHessian pass is read from
+// the 96-byte table the test hook exposes: dgs_handle::vox_dbg.)
+struct __attribute__((aligned(16))) VoxelStrictRec {
+  double mean[3];
+  float C[9];   // row-major float(icov)
+  float pad;
+};
+static_assert(sizeof(VoxelStrictRec) == 64, "VoxelStrictRec must be 64 bytes");
+
 struct VoxelGrid {
   int min_b[3];
   int max_b[3];
@@ -85,6 +96,16 @@ struct NdtPair {
   NdtSolver s;
   float final_T[16];   // column-major, = final_transformation_
   double traj[kTrajCap][6];
+  // need_hessian == 2 (computeHessian in PCL's double form, dgs_params.ndt_hessian_recompute_double): the double angle vectors
+  // j_ang_a_ .. h_ang_f3_ of the evaluation's pose, which upstream keeps beside the float matrices
+  double jang_d[8][3];
+  double hang_d[15][3];
+  // fused launches of the upstream order (ndt_strict.h): two kernels per round -- [0] evaluation kinds 0 / 1, [1] kind 2 -- and the pair
+  // takes part in the kernel of type t of round r while r <= serve[t].  Its closing workgroup raises the word of the kernel that serves
+  // the evaluation it has just queued; a word only ever grows, and never past the round that reads it plus one, so every workgroup of a
+  // running launch sees the same set of pairs whatever the moment it looks (the default order's last_launch plays this part there).
+  int serve[2];
+  int pad_serve[2];
 };
 
 // ---- per-pair GICP optimiser state (fast_gicp::LsqRegistration) -------------------------------
@@ -149,6 +170,8 @@ struct NdtConsts {
   int max_iterations, line_search, mt_max_step_iterations, fix_hessian_d1;
   int search_method;
   int strict_order;  // dgs_ndt_strict_order
+  int newton_solver;     // upstream orders: 1 = Eigen's two-sided JacobiSVD sequence (solve6.h jsvd_solve6_wave), 0 = one-sided Hestenes Jacobi
+  int hessian_double;    // upstream orders: computeStepLengthMT's closing computeHessian in PCL's double form (evaluation kind 2)
 };
 
 struct NdtInit {  // host -> device per pair, per align

@@ -258,6 +258,9 @@ int dgs_params_init(dgs_params* p, int32_t method) {
   p->ndt_mt_max_step_iterations = 10;
   p->ndt_fix_hessian_d1 = 0;
   p->ndt_strict_order = DGS_NDT_ORDER_FAST;
+  p->ndt_newton_solver = 1;
+  p->ndt_hessian_recompute_double = 1;
+  p->ndt_guess_rotation_polar = 1;
   p->gicp_max_correspondence_distance = 2.5;
   p->gicp_rotation_epsilon = 2e-3;
   p->gicp_lm_init_lambda_factor = 1e-9;
@@ -340,7 +343,7 @@ void dgs_destroy(dgs_handle* h) {
   h->batch_slab.release();
   for (auto& c : h->batch_clouds) c.release();
   h->gitems.release(); h->vvox.release(); h->vcell2vox.release();
-  h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_count.release(); h->vox_valid.release();
+  h->cell2vox.release(); h->vox.release(); h->vox_centroid.release(); h->vox_dbg.release(); h->vox_strict.release(); h->vox_count.release(); h->vox_valid.release();
   h->key_in.release(); h->key_out.release(); h->val_in.release(); h->val_out.release(); h->run_keys.release();
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->vg_run_keys.release(); h->vg_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
   h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->ndt_queue.release(); h->ndt_ring.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
@@ -830,6 +833,17 @@ int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, doubl
   if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
   if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
   return ndt_probe(h, p6, T16, score, grad6, hess36);
+}
+
+int dgs_ndt_hessian_double(dgs_handle* h, const double* p6, double* hess36) {
+  if (!h || !p6 || !hess36) return DGS_ERR_INVALID_ARGUMENT;
+  h->err.clear();
+  if (set_device(h)) return DGS_ERR_HIP;
+  if (h->prm.method != DGS_METHOD_NDT || h->prm.ndt_strict_order == DGS_NDT_ORDER_FAST || !h->prm.ndt_hessian_recompute_double) return DGS_ERR_UNSUPPORTED;
+  if (!h->have_target || h->nt == 0) return DGS_ERR_NO_TARGET;
+  if (!h->have_source || h->ns == 0) return DGS_ERR_NO_SOURCE;
+  double score, g6[6];
+  return ndt_probe(h, p6, nullptr, &score, g6, hess36, 2);
 }
 
 int dgs_find_loop_candidates(dgs_handle* h, const double* accum_distance, const double* xy, int64_t n, int32_t on_device, double new_accum_distance,

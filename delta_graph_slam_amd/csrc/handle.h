@@ -128,7 +128,8 @@ struct dgs_handle {
   dgs::DevBuf<int> cell2vox;
   dgs::DevBuf<dgs::VoxelRec> vox;
   dgs::DevBuf<float4> vox_centroid;
-  dgs::DevBuf<double> vox_dbg;       // per occupied voxel: mean[3], icov[9]  (test hook)
+  dgs::DevBuf<double> vox_dbg;       // per occupied voxel: mean[3], icov[9]  (test hook; double-precision computeHessian pass)
+  dgs::DevBuf<dgs::VoxelStrictRec> vox_strict;   // per occupied voxel: mean, float(icov) 3 x 3 (upstream evaluation orders)
   dgs::DevBuf<int> vox_count;        // points per occupied voxel
   dgs::DevBuf<int> vox_valid;
   dgs::DevBuf<uint32_t> key_in, key_out, val_in, val_out, run_keys;
@@ -140,6 +141,7 @@ struct dgs_handle {
   dgs::DevBuf<unsigned char> cub_temp;
   int64_t grid_cells = 0;
   int64_t n_occupied = 0, n_valid = 0;  // filled lazily by counts query
+  int64_t n_occupied_bound = 0;         // target points of the voxel model = an upper bound of its occupied voxels (known without a device round trip)
   bool counts_stale = true;
 
   // ---- NDT optimiser
@@ -260,7 +262,7 @@ int cloud_minmax_device(dgs_handle* h, const float4* pts, int64_t n, float** d_o
 int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* d_src_ptrs_host, const int* sizes_host,
                     const float* guesses16, dgs_result* results);
 int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len);
-int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36);
+int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36, int kind = 1);   // kind 2: the double-precision computeHessian pass
 // nn_bvh.hip
 int bvh_build(dgs_handle* h, Bvh& bvh, const float4* pts, int64_t n, hipStream_t st = nullptr, bool kd_order = false);  // st: default the handle's stream; kd_order: median-split order (slower build, faster queries)
 int nn_fitness(dgs_handle* h, const float4* src, int64_t n, const float* T16, double max_range, double inlier_sq,

@@ -643,84 +643,6 @@ __device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T,
   for (int k = 0; k < 36; k++) out[7 + k] = h_pt[k];
 }
 
-// ROWS = false (ndt_strict_order 1): per-thread double totals over a strided set of points, block sums in a fixed order, one
-// 48-double row per workgroup.  ROWS = true (ndt_strict_order 2): the 43 per-point totals go to HBM, column-major per pair
-// ([43][max_n]), for the sequential index-order sum of ndt_strict_seqsum_kernel.
-template <int SEARCH, bool ROWS, bool LITERAL>
-__global__ __launch_bounds__(kBlock, 2) void ndt_derivatives_strict_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
-                                                                        const NdtPair* __restrict__ pairs, const VoxelGrid g,
-                                                                        const double* __restrict__ vtab, const double gauss_d1, const float gd2,
-                                                                        const int leaf_pow2, double* __restrict__ partials, double* __restrict__ rows,
-                                                                        const int max_n, const int n_pairs, const int cap_blocks,
-                                                                        int* __restrict__ pair_blocks) {
-  int pair, slice, blocks_per_pair;
-  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, blocks_per_pair)) return;
-  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
-  const NdtPair& st = pairs[pair];
-  const float4* __restrict__ src = src_ptrs[pair];
-  const int n = src_sizes[pair];
-  const bool need_h = st.need_hessian != 0;
-  float T[12];
-#pragma unroll
-  for (int k = 0; k < 12; k++) T[k] = st.T[k];
-  double acc[kStrictAccum];
-#pragma unroll
-  for (int k = 0; k < kStrictAccum; k++) acc[k] = 0.0;
-  const int ncol = need_h ? kStrictAccum : 7;
-  for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
-    double o[kStrictAccum];
-    ndt_point_strict<SEARCH, LITERAL>(src[i], T, st, g, vtab, gauss_d1, gd2, leaf_pow2, need_h, o);
-    if (ROWS) {
-      double* __restrict__ col = rows + (size_t)pair * kStrictAccum * max_n + i;
-      for (int k = 0; k < ncol; k++) col[(size_t)k * max_n] = o[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < kStrictAccum; k++) acc[k] += o[k];
-    }
-  }
-  if (ROWS) return;
-  __shared__ double sm[kBlock / kWave][kStrictPad];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kStrictAccum; k++) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) sm[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kStrictPad) {
-    double v = 0.0;
-    if (threadIdx.x < kStrictAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
-    partials[((size_t)pair * cap_blocks + slice) * kStrictPad + threadIdx.x] = v;
-  }
-}
-
-// ndt_strict_order 2: upstream's final loop -- score / gradient / Hessian entries summed over the points in index order, one
-// lane per entry (a dependent chain of n double additions: this mode exists to prove bit-parity, not to be fast)
-__global__ __launch_bounds__(kWave) void ndt_strict_seqsum_kernel(const NdtPair* __restrict__ pairs, const int* __restrict__ src_sizes,
-                                                                  const double* __restrict__ rows, const int max_n, double* __restrict__ totals) {
-  const int pair = blockIdx.x;
-  const NdtPair& st = pairs[pair];
-  if (!st.active) return;
-  const int ncol = st.need_hessian ? kStrictAccum : 7;
-  const int c = threadIdx.x;
-  if (c >= kStrictPad) return;
-  double v = 0.0;
-  if (c < ncol) {
-    const int n = src_sizes[pair];
-    const double* __restrict__ col = rows + ((size_t)pair * kStrictAccum + c) * max_n;
-    int i = 0;
-    for (; i + 8 <= n; i += 8) {
-      double t[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) t[u] = col[i + u];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v += t[u];
-    }
-    for (; i < n; i++) v += col[i];
-  }
-  totals[(size_t)pair * kStrictPad + c] = v;
-}
-
 // ================================================================================================ solver
 // float transform + angle-derivative tables of pose x (computeAngleDerivatives: double trig, |angle| < 1e-4 snap),
 // written to the pair's HBM record by lane 0 (`writer`); every lane computes the same values.
@@ -817,6 +739,33 @@ __device__ __forceinline__ void write_evaluation(NdtPair* st, NdtPair* hdr, NdtS
     hdr_put<COH>(&H[13][0], (float)(-cx * sz - sx * sy * cz)); hdr_put<COH>(&H[13][1], (float)(-cx * cz + sx * sy * sz)); hdr_put<COH>(&H[13][2], 0.f);              // f2
     hdr_put<COH>(&H[14][0], (float)(-sx * sz + cx * sy * cz)); hdr_put<COH>(&H[14][1], (float)(-cx * sy * sz - sx * cz)); hdr_put<COH>(&H[14][2], 0.f);              // f3
     }
+    if (need_hessian == 2) {   // computeHessian in PCL's double form reads the double angle vectors (never inside the queue kernel: plain stores)
+      double (*Jd)[3] = hdr->jang_d;
+      Jd[0][0] = (-sx * sz + cx * sy * cz); Jd[0][1] = (-sx * cz - cx * sy * sz); Jd[0][2] = (-cx * cy);
+      Jd[1][0] = (cx * sz + sx * sy * cz);  Jd[1][1] = (cx * cz - sx * sy * sz);  Jd[1][2] = (-sx * cy);
+      Jd[2][0] = (-sy * cz);                Jd[2][1] = (sy * sz);                 Jd[2][2] = (cy);
+      Jd[3][0] = (sx * cy * cz);            Jd[3][1] = (-sx * cy * sz);           Jd[3][2] = (sx * sy);
+      Jd[4][0] = (-cx * cy * cz);           Jd[4][1] = (cx * cy * sz);            Jd[4][2] = (-cx * sy);
+      Jd[5][0] = (-cy * sz);                Jd[5][1] = (-cy * cz);                Jd[5][2] = 0.0;
+      Jd[6][0] = (cx * cz - sx * sy * sz);  Jd[6][1] = (-cx * sz - sx * sy * cz); Jd[6][2] = 0.0;
+      Jd[7][0] = (sx * cz + cx * sy * sz);  Jd[7][1] = (cx * sy * cz - sx * sz);  Jd[7][2] = 0.0;
+      double (*Hd)[3] = hdr->hang_d;
+      Hd[0][0] = (-cx * sz - sx * sy * cz); Hd[0][1] = (-cx * cz + sx * sy * sz); Hd[0][2] = (sx * cy);
+      Hd[1][0] = (-sx * sz + cx * sy * cz); Hd[1][1] = (-cx * sy * sz - sx * cz); Hd[1][2] = (-cx * cy);
+      Hd[2][0] = (cx * cy * cz);            Hd[2][1] = (-cx * cy * sz);           Hd[2][2] = (cx * sy);
+      Hd[3][0] = (sx * cy * cz);            Hd[3][1] = (-sx * cy * sz);           Hd[3][2] = (sx * sy);
+      Hd[4][0] = (-sx * cz - cx * sy * sz); Hd[4][1] = (sx * sz - cx * sy * cz);  Hd[4][2] = 0.0;
+      Hd[5][0] = (cx * cz - sx * sy * sz);  Hd[5][1] = (-sx * sy * cz - cx * sz); Hd[5][2] = 0.0;
+      Hd[6][0] = (-cy * cz);                Hd[6][1] = (cy * sz);                 Hd[6][2] = (c.fix_hessian_d1 ? -sy : sy);
+      Hd[7][0] = (-sx * sy * cz);           Hd[7][1] = (sx * sy * sz);            Hd[7][2] = (sx * cy);
+      Hd[8][0] = (cx * sy * cz);            Hd[8][1] = (-cx * sy * sz);           Hd[8][2] = (-cx * cy);
+      Hd[9][0] = (sy * sz);                 Hd[9][1] = (sy * cz);                 Hd[9][2] = 0.0;
+      Hd[10][0] = (-sx * cy * sz);          Hd[10][1] = (-sx * cy * cz);          Hd[10][2] = 0.0;
+      Hd[11][0] = (cx * cy * sz);           Hd[11][1] = (cx * cy * cz);           Hd[11][2] = 0.0;
+      Hd[12][0] = (-cy * cz);               Hd[12][1] = (cy * sz);                Hd[12][2] = 0.0;
+      Hd[13][0] = (-cx * sz - sx * sy * cz); Hd[13][1] = (-cx * cz + sx * sy * sz); Hd[13][2] = 0.0;
+      Hd[14][0] = (-sx * sz + cx * sy * cz); Hd[14][1] = (-cx * sy * sz - sx * cz); Hd[14][2] = 0.0;
+    }
     hdr_put_int<COH>(&hdr->need_hessian, need_hessian);
   }
 #pragma unroll
@@ -877,13 +826,17 @@ __device__ inline double dot6(const double* a, const double* b) {
 
 // Starts one outer iteration from (score, grad, hess) at s.p.  Returns true when an evaluation was queued,
 // false when the iteration finished without one (zero step) or the registration ended.
-template <bool SVD_REGS, bool COH = false>
+// STRICT: the upstream evaluation orders -- JacobiSVD(H).solve(-g) in the CPU checker's sequence of operations (Eigen's two-sided
+// Jacobi across the wave, or rounds 2-3's one-sided Jacobi: dgs_params.ndt_newton_solver); otherwise the default order's Gauss-Jordan
+// step.  A template argument, not a run-time test, so that the default order's fused kernel carries none of the SVD code.
+template <bool STRICT, bool SVD_REGS, bool COH = false>
 __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer) {
   double neg_g[6], delta[6], rc;
 #pragma unroll
   for (int k = 0; k < 6; k++) neg_g[k] = -s.grad[k];
-  if (c.strict_order) {  // JacobiSVD(H).solve(-g), the sequence of operations of the CPU checker
-    if (SVD_REGS) svd_solve6_regs_dev(s.hess, neg_g, delta, 1e-17, 60);
+  if (STRICT) {
+    if (c.newton_solver) jsvd_solve6_wave(s.hess, neg_g, delta);
+    else if (SVD_REGS) svd_solve6_regs_dev(s.hess, neg_g, delta, 1e-17, 60);
     else svd_solve6_dev(s.hess, neg_g, delta, 1e-17, 60);
   } else {
     gj_solve6_columns(s.hess, s.grad, delta, &rc);
@@ -977,7 +930,7 @@ __device__ __forceinline__ void queue_trial(NdtPair* st, NdtPair* hdr, NdtSolver
 // Consumes one evaluation result (already stored in s.score/grad/hess) and advances the state machine until
 // the next evaluation is queued or the registration is finished.  Executed by all lanes of one wave in lock step.
 // SVD_REGS: the stand-alone solve launch of the validation modes keeps the SVD workspace in registers (solve6.h)
-template <bool SVD_REGS = false, bool COH = false>
+template <bool SVD_REGS = false, bool COH = false, bool STRICT = false>
 __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer) {
   s.evaluations++;
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
@@ -1017,7 +970,7 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
         double x[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) x[k] = s.x_t[k];
-        write_evaluation<true, COH>(st, hdr, s, c, x, 1, false, writer);
+        write_evaluation<true, COH>(st, hdr, s, c, x, (STRICT && c.hessian_double) ? 2 : 1, false, writer);
         s.phase = PH_MT_HESSIAN;
         return;
       }
@@ -1033,12 +986,129 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
     if (iteration_open) {
       if (end_iteration(st, s, c, writer)) return;
     }
-    if (begin_iteration<SVD_REGS, COH>(st, hdr, s, c, writer)) return;  // evaluation queued
+    if (begin_iteration<STRICT, SVD_REGS, COH>(st, hdr, s, c, writer)) return;  // evaluation queued
     if (s.phase == PH_DONE) return;
     iteration_open = true;                          // zero-step iteration: close it and try again
   }
   s.converged = 0;
   s.phase = PH_DONE;
+}
+
+#include "ndt_strict.h"   // ndt_strict_order 1: the upstream-order evaluation as a fused launch (uses ndt_advance above)
+
+// Round 2's validation kernel, kept for ndt_strict_order 2 (ROWS = true; order 1 runs ndt_strict_kernel, ndt_strict.h).  ROWS = false:
+// per-thread double totals over a strided set of points, block sums in a fixed order, one 48-double row per workgroup.  ROWS = true: the 43 per-point totals go to HBM, column-major per pair
+// ([43][max_n]), for the sequential index-order sum of ndt_strict_seqsum_kernel.
+template <int SEARCH, bool ROWS, bool LITERAL>
+__global__ __launch_bounds__(kBlock, 2) void ndt_derivatives_strict_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes,
+                                                                        const NdtPair* __restrict__ pairs, const VoxelGrid g,
+                                                                        const double* __restrict__ vtab, const double gauss_d1, const float gd2,
+                                                                        const int leaf_pow2, double* __restrict__ partials, double* __restrict__ rows,
+                                                                        const int max_n, const int n_pairs, const int cap_blocks,
+                                                                        int* __restrict__ pair_blocks, const double gauss_d2, const size_t rows_pair_stride) {
+  int pair, slice, blocks_per_pair;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, blocks_per_pair)) return;
+  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
+  const NdtPair& st = pairs[pair];
+  const float4* __restrict__ src = src_ptrs[pair];
+  const int n = src_sizes[pair];
+  const bool need_h = st.need_hessian != 0;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st.T[k];
+  double acc[kStrictAccum];
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) acc[k] = 0.0;
+  const int ncol = need_h ? kStrictAccum : 7;
+  if (ROWS && st.need_hessian == 2) {
+    // computeHessian in PCL's double form (evaluation kind 2): every (point, voxel) term to HBM, entry-major [36][n * NB], for the
+    // sequential sum in upstream's order (ndt_strict_seqsum_kernel)
+    constexpr int NB = Offsets<SEARCH>::N;
+    const size_t row_stride = (size_t)max_n * NB;
+    for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
+      const float4 x = src[i];
+      float xt[3];
+      xt[0] = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
+      xt[1] = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
+      xt[2] = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
+      int vids[NB];
+      const unsigned mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
+      strict_point_hd<SEARCH, true>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, rows + (size_t)pair * rows_pair_stride + (size_t)i * NB, row_stride);
+    }
+    return;
+  }
+  for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
+    double o[kStrictAccum];
+    ndt_point_strict<SEARCH, LITERAL>(src[i], T, st, g, vtab, gauss_d1, gd2, leaf_pow2, need_h, o);
+    if (ROWS) {
+      double* __restrict__ col = rows + (size_t)pair * rows_pair_stride + i;
+      for (int k = 0; k < ncol; k++) col[(size_t)k * max_n] = o[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < kStrictAccum; k++) acc[k] += o[k];
+    }
+  }
+  if (ROWS) return;
+  __shared__ double sm[kBlock / kWave][kStrictPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) sm[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kStrictPad) {
+    double v = 0.0;
+    if (threadIdx.x < kStrictAccum) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    partials[((size_t)pair * cap_blocks + slice) * kStrictPad + threadIdx.x] = v;
+  }
+}
+
+// ndt_strict_order 2: upstream's final loop -- score / gradient / Hessian entries summed over the points in index order, one
+// lane per entry (a dependent chain of n double additions: this mode exists to prove bit-parity, not to be fast)
+__global__ __launch_bounds__(kWave) void ndt_strict_seqsum_kernel(const NdtPair* __restrict__ pairs, const int* __restrict__ src_sizes,
+                                                                  const double* __restrict__ rows, const int max_n, double* __restrict__ totals,
+                                                                  const size_t rows_pair_stride, const int nb_slots) {
+  const int pair = blockIdx.x;
+  const NdtPair& st = pairs[pair];
+  if (!st.active) return;
+  const int c = threadIdx.x;
+  if (c >= kStrictPad) return;
+  if (st.need_hessian == 2) {
+    // computeHessian (kind 2): the Hessian entries alone, every (point, voxel slot) term in upstream's order
+    double v = 0.0;
+    if (c >= 7 && c < kStrictAccum) {
+      const size_t n = (size_t)src_sizes[pair] * nb_slots;
+      const double* __restrict__ col = rows + (size_t)pair * rows_pair_stride + (size_t)(c - 7) * ((size_t)max_n * nb_slots);
+      size_t i = 0;
+      for (; i + 8 <= n; i += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = col[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u];
+      }
+      for (; i < n; i++) v += col[i];
+    }
+    totals[(size_t)pair * kStrictPad + c] = v;
+    return;
+  }
+  const int ncol = st.need_hessian ? kStrictAccum : 7;
+  double v = 0.0;
+  if (c < ncol) {
+    const int n = src_sizes[pair];
+    const double* __restrict__ col = rows + (size_t)pair * rows_pair_stride + (size_t)c * max_n;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t[u] = col[i + u];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v += t[u];
+    }
+    for (; i < n; i++) v += col[i];
+  }
+  totals[(size_t)pair * kStrictPad + c] = v;
 }
 
 // Sums a pair's partial rows in slice order and advances its optimiser by one evaluation; executed by one whole workgroup.
@@ -1141,7 +1211,7 @@ __device__ __forceinline__ bool ndt_close_evaluation(NdtPair* st, const double* 
 }
 
 __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__ pairs, const double* __restrict__ partials, const int cap_blocks,
-                                                           const int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter,
+                                                           int* __restrict__ pair_blocks, const NdtConsts c, int* __restrict__ done_counter,
                                                            const double* __restrict__ strict_totals, const int strict_from_rows) {
   const int pair = blockIdx.x;
   NdtPair* st = pairs + pair;
@@ -1150,7 +1220,11 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
     ndt_close_evaluation(st, partials + (size_t)pair * cap_blocks * kAccumPad, pair_blocks[pair], c, done_counter, -1);
     return;
   }
-  // validation modes: the sums of this evaluation were formed by ndt_strict_reduce / ndt_strict_seqsum
+  // validation modes: the sums of this evaluation were formed by ndt_strict_kernel's rows / ndt_strict_seqsum.  A pair that the
+  // derivative launch in front of this one did not evaluate (the launch served the other evaluation kind, ndt_strict.h) has no rows.
+  if (strict_from_rows) {
+    if (pair_blocks[pair] == 0) return;
+  }
   __shared__ NdtSolver s_lds;
   NdtSolver& s = s_lds;
   __shared__ double tot[kStrictPad];
@@ -1182,15 +1256,18 @@ __global__ __launch_bounds__(kBlock) void ndt_solve_kernel(NdtPair* __restrict__
   __syncthreads();
   if (threadIdx.x >= kWave) return;
   const bool writer = threadIdx.x == 0;
-  s.score = tot[0];
+  if (need_h != 2) {   // kind 2 (computeHessian alone) leaves score and gradient as the last trial left them
+    s.score = tot[0];
 #pragma unroll
-  for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];
+    for (int k = 0; k < 6; k++) s.grad[k] = tot[1 + k];
+  }
   if (need_h) {
 #pragma unroll
     for (int k = 0; k < 36; k++) s.hess[k] = tot[7 + k];  // upstream's full 6x6 (not exactly symmetric in float)
   }
-  ndt_advance<true>(st, st, s, c, writer);
+  ndt_advance<true, false, true>(st, st, s, c, writer);
   if (writer) {
+    if (strict_from_rows) pair_blocks[pair] = 0;   // consumed
     st->s = s;
     if (s.phase == PH_DONE) {
       st->active = 0;
@@ -1436,7 +1513,7 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   for (int k = 0; k < 36; k++) s.hess[k] = 0;
   double x[6];
   for (int k = 0; k < 6; k++) x[k] = in.p0[k];
-  write_evaluation<false>(st, st, s, c, x, 1, false, true);
+  write_evaluation<false>(st, st, s, c, x, probe == 2 ? 2 : 1, false, true);   // probe 2: the test hook of the double-precision computeHessian pass
   // the first evaluation transforms the cloud by the GUESS matrix itself (computeTransformation)
   const float* G = in.guess;
   st->T[0] = G[0]; st->T[1] = G[4]; st->T[2] = G[8];  st->T[3] = G[12];
@@ -1447,6 +1524,8 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   st->active = 1;
   st->last_launch = 0x7FFFFFFF;
   st->ticket = 0;
+  st->serve[0] = 0;    // upstream order, fused: the first evaluation (kind 1) is served by round 0's first kernel
+  st->serve[1] = -1;
   if (queue) {   // queue kernel: the record slot of round 0
     const int* from = reinterpret_cast<const int*>(st);
     int* to = reinterpret_cast<int*>(queue_slot(ring, ring_rounds, i, 0));
@@ -1495,6 +1574,120 @@ static void euler_angles_012(const float* T, float res[3]) {
   res[2] = -res[2];
 }
 
+// Eigen::Transform<float, 3, Affine>::rotation() of the guess (dgs_params.ndt_guess_rotation_polar): computeRotationScaling, i.e. a
+// 3 x 3 float JacobiSVD (Eigen 3.3's two-sided Jacobi: the sequence of solve6.h's jsvd, here in float on the host, once per align),
+// x = det(U V^T), U.col(0) /= x, R = U V^T.  Every operation individually rounded (contraction is off in this part of the file).
+// [UPSTREAM-RECALL: Eigen/src/Geometry/Transform.h, Eigen/src/SVD/JacobiSVD.h; the CPU checker carries its own statement.]  R: row-major.
+static void affine_rotation_f32(const float* T_colmajor16, float* R) {
+  constexpr int N = 3;
+  const float precision = 2.f * FLT_EPSILON, tiny = FLT_MIN;
+  float W[9], U[9], V[9];
+  float scale = 0.f;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) { W[r * 3 + c] = T_colmajor16[c * 4 + r]; scale = std::fabs(W[r * 3 + c]) > scale ? std::fabs(W[r * 3 + c]) : scale; }
+  if (scale == 0.f) scale = 1.f;
+  for (int i = 0; i < 9; i++) { W[i] = W[i] / scale; U[i] = V[i] = (i % 4 == 0) ? 1.f : 0.f; }
+  float max_diag = 0.f;
+  for (int i = 0; i < N; i++) { const float a = std::fabs(W[i * 4]); if (a > max_diag) max_diag = a; }
+  bool finished = false;
+  for (int sweep = 0; sweep < 64 && !finished; sweep++) {
+    finished = true;
+    for (int p = 1; p < N; p++)
+      for (int q = 0; q < p; q++) {
+        const float pm = precision * max_diag;
+        const float threshold = tiny > pm ? tiny : pm;
+        if (!(std::fabs(W[p * N + q]) > threshold || std::fabs(W[q * N + p]) > threshold)) continue;
+        finished = false;
+        float m00 = W[p * N + p], m01 = W[p * N + q], m10 = W[q * N + p], m11 = W[q * N + q];
+        const float t = m00 + m11, d = m10 - m01;
+        float r1c, r1s;
+        if (std::fabs(d) < tiny) { r1s = 0.f; r1c = 1.f; }
+        else {
+          const float u = t / d;
+          const float tmp = std::sqrt(1.f + u * u);
+          r1s = 1.f / tmp;
+          r1c = u / tmp;
+        }
+        if (!(r1c == 1.f && r1s == 0.f)) {
+          const float x0 = m00, y0 = m10, x1 = m01, y1 = m11;
+          m00 = r1c * x0 + r1s * y0; m10 = -r1s * x0 + r1c * y0;
+          m01 = r1c * x1 + r1s * y1; m11 = -r1s * x1 + r1c * y1;
+        }
+        float jrc, jrs;
+        {
+          const float deno = 2.f * std::fabs(m01);
+          if (deno < tiny) { jrc = 1.f; jrs = 0.f; }
+          else {
+            const float tau = (m00 - m11) / deno;
+            const float w = std::sqrt(tau * tau + 1.f);
+            const float tt = (tau > 0.f) ? 1.f / (tau + w) : 1.f / (tau - w);
+            const float sign_t = tt > 0.f ? 1.f : -1.f;
+            const float nn = 1.f / std::sqrt(tt * tt + 1.f);
+            jrs = -sign_t * (m01 / std::fabs(m01)) * std::fabs(tt) * nn;
+            jrc = nn;
+          }
+        }
+        const float jtc = jrc, jts = -jrs;
+        const float jlc = r1c * jtc - r1s * jts;
+        const float jls = r1c * jts + r1s * jtc;
+        if (!(jlc == 1.f && jls == 0.f)) {
+          for (int i = 0; i < N; i++) {
+            const float xi = W[p * N + i], yi = W[q * N + i];
+            W[p * N + i] = jlc * xi + jls * yi;
+            W[q * N + i] = -jls * xi + jlc * yi;
+          }
+          for (int i = 0; i < N; i++) {
+            const float xi = U[i * N + p], yi = U[i * N + q];
+            U[i * N + p] = jlc * xi + jls * yi;
+            U[i * N + q] = -jls * xi + jlc * yi;
+          }
+        }
+        if (!(jrc == 1.f && -jrs == 0.f)) {
+          const float c = jrc, s = -jrs;
+          for (int i = 0; i < N; i++) {
+            const float xi = W[i * N + p], yi = W[i * N + q];
+            W[i * N + p] = c * xi + s * yi;
+            W[i * N + q] = -s * xi + c * yi;
+          }
+          for (int i = 0; i < N; i++) {
+            const float xi = V[i * N + p], yi = V[i * N + q];
+            V[i * N + p] = c * xi + s * yi;
+            V[i * N + q] = -s * xi + c * yi;
+          }
+        }
+        const float app = std::fabs(W[p * N + p]), aqq = std::fabs(W[q * N + q]);
+        const float mx = app < aqq ? aqq : app;
+        if (max_diag < mx) max_diag = mx;
+      }
+  }
+  float sv[3];
+  for (int i = 0; i < N; i++) {
+    const float a = W[i * 4];
+    sv[i] = std::fabs(a) * scale;
+    if (a < 0.f) for (int k = 0; k < N; k++) U[k * N + i] = -U[k * N + i];
+  }
+  for (int i = 0; i < N; i++) {   // descending order: first maximum of the tail, column swaps
+    int pos = 0;
+    float best = sv[i];
+    for (int k = 1; k < N - i; k++) if (sv[i + k] > best) { best = sv[i + k]; pos = k; }
+    if (best == 0.f) break;
+    if (pos) {
+      pos += i;
+      std::swap(sv[i], sv[pos]);
+      for (int k = 0; k < N; k++) { std::swap(U[k * N + i], U[k * N + pos]); std::swap(V[k * N + i], V[k * N + pos]); }
+    }
+  }
+  auto prod = [&](const float* M, int i, int j) { return M[i * 3 + 0] * V[j * 3 + 0] + M[i * 3 + 1] * V[j * 3 + 1] + M[i * 3 + 2] * V[j * 3 + 2]; };
+  float UVt[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) UVt[i * 3 + j] = prod(U, i, j);
+  auto det3h = [&](int a, int b, int c) { return UVt[0 * 3 + a] * (UVt[1 * 3 + b] * UVt[2 * 3 + c] - UVt[1 * 3 + c] * UVt[2 * 3 + b]); };
+  const float x = det3h(0, 1, 2) - det3h(1, 0, 2) + det3h(2, 0, 1);
+  for (int k = 0; k < 3; k++) U[k * 3 + 0] /= x;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[i * 3 + j] = prod(U, i, j);
+}
+
 static void fill_consts(dgs_handle* h) {
   const dgs_params& p = h->prm;
   const double c1 = 10.0 * (1.0 - p.ndt_outlier_ratio);
@@ -1511,6 +1704,8 @@ static void fill_consts(dgs_handle* h) {
   c.fix_hessian_d1 = p.ndt_fix_hessian_d1;
   c.search_method = p.ndt_search_method;
   c.strict_order = p.ndt_strict_order;
+  c.newton_solver = p.ndt_newton_solver;
+  c.hessian_double = (p.ndt_strict_order != DGS_NDT_ORDER_FAST && p.ndt_hessian_recompute_double) ? 1 : 0;
 }
 
 struct NdtLaunch {
@@ -1522,41 +1717,92 @@ struct NdtLaunch {
   int queue_base;    // queue kernel: slices of a pair's first rounds (ndt_queue_slices)
 };
 
+// per-pair stride (doubles) of the ndt_strict_order 2 table: 43 per-point totals, or -- with the double-precision computeHessian pass --
+// 36 entries x (point, voxel slot) terms
+static size_t strict_rows_pair_stride(const dgs_handle* h, const NdtLaunch& L) {
+  size_t s = (size_t)kStrictAccum * L.max_n;
+  if (h->consts.hessian_double) {
+    const int nb = (h->consts.search_method == DGS_NDT_DIRECT1) ? 1 : (h->consts.search_method == DGS_NDT_DIRECT7 ? 7 : 27);
+    s = std::max(s, (size_t)36 * L.max_n * nb);
+  }
+  return s;
+}
+
+// ndt_strict_order 2: per-point totals / per-term table to HBM (round 2's kernel), then the sequential sums
 template <int SEARCH>
-static void launch_strict(dgs_handle* h, const NdtLaunch& L, const dim3 grid, const int leaf_pow2) {
+static void launch_strict_rows(dgs_handle* h, const NdtLaunch& L, const dim3 grid, const int leaf_pow2) {
   const double gd1 = h->consts.gauss_d1;
   const float gd2 = (float)h->consts.gauss_d2;
   static const bool literal = std::getenv("DGS_NDT_STRICT_LITERAL") && std::atoi(std::getenv("DGS_NDT_STRICT_LITERAL")) != 0;
-#define DGS_LAUNCH_STRICT(ROWS, LIT)                                                                                                                       \
-  hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, ROWS, LIT>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, \
-                     h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr)
-  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) {
-    if (literal) DGS_LAUNCH_STRICT(true, true); else DGS_LAUNCH_STRICT(true, false);
-  } else {
-    if (literal) DGS_LAUNCH_STRICT(false, true); else DGS_LAUNCH_STRICT(false, false);
-  }
+  const size_t stride = strict_rows_pair_stride(h, L);
+#define DGS_LAUNCH_STRICT(LIT)                                                                                                                             \
+  hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, true, LIT>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, \
+                     h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr,     \
+                     h->consts.gauss_d2, stride)
+  if (literal) DGS_LAUNCH_STRICT(true); else DGS_LAUNCH_STRICT(false);
 #undef DGS_LAUNCH_STRICT
+  hipLaunchKernelGGL(ndt_strict_seqsum_kernel, dim3(L.n_pairs), dim3(kWave), 0, h->stream, h->pairs.ptr, h->src_sizes.ptr, h->strict_rows.ptr, L.max_n,
+                     h->strict_totals.ptr, stride, Offsets<SEARCH>::N);
+}
+
+// ndt_strict_order 1: ndt_strict_kernel (ndt_strict.h); launch >= 0: fused (derivatives + closing workgroups), < 0: derivatives only.
+// hd: the instantiation for the pairs waiting for the double-precision computeHessian pass (evaluation kind 2).
+// DGS_NDT_STRICT_KERNEL=2: the lane-per-point kernels (two launches per round); default 3: the item-compacted kernel (one launch per round)
+static int strict_kernel_version() {
+  static const int v = std::getenv("DGS_NDT_STRICT_KERNEL") ? std::atoi(std::getenv("DGS_NDT_STRICT_KERNEL")) : 3;
+  return v == 2 ? 2 : 3;
+}
+
+template <int SEARCH>
+static void launch_strict_sums(dgs_handle* h, const NdtLaunch& L, const dim3 grid, const int leaf_pow2, const int launch, const bool hd) {
+  if (strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25)) {
+    if (hd && launch >= 0) return;   // one kernel serves every kind (launch < 0: the test hook asks for the kind it has set up)
+    if (launch >= 0)
+      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
+                         h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
+                         h->done_flags, launch);
+    else
+      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, false>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
+                         h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
+                         h->done_counter.ptr, launch);
+    return;
+  }
+#define DGS_LAUNCH_SS(FUSED, HD, FLAGS)                                                                                                                          \
+  hipLaunchKernelGGL((ndt_strict_kernel<SEARCH, FUSED, HD>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr, \
+                     h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts, FLAGS, launch)
+  if (launch >= 0) {
+    if (hd) DGS_LAUNCH_SS(true, true, h->done_flags); else DGS_LAUNCH_SS(true, false, h->done_flags);
+  } else {
+    if (hd) DGS_LAUNCH_SS(false, true, h->done_counter.ptr); else DGS_LAUNCH_SS(false, false, h->done_counter.ptr);
+  }
+#undef DGS_LAUNCH_SS
 }
 
 // launch >= 0: fused launch number `launch` of this align (derivatives + closing workgroups); < 0: derivatives only
-static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -1) {
+static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -1, bool hd = false) {
   const dim3 grid(L.total_blocks), block(kBlock);
   const double gd1 = h->consts.gauss_d1;
   const float gd2 = (float)h->consts.gauss_d2;
   int fe = 0;
   const int leaf_pow2 = (std::frexp(h->grid.leaf, &fe) == 0.5f) ? 1 : 0;
   int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES);
-  if (h->consts.strict_order != DGS_NDT_ORDER_FAST) {
+  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) {
     switch (h->consts.search_method) {
-      case DGS_NDT_DIRECT1: launch_strict<DGS_NDT_DIRECT1>(h, L, grid, leaf_pow2); break;
-      case DGS_NDT_DIRECT26: launch_strict<DGS_NDT_DIRECT26>(h, L, grid, leaf_pow2); break;
-      case DGS_NDT_KDTREE: launch_strict<DGS_NDT_KDTREE>(h, L, grid, leaf_pow2); break;
-      default: launch_strict<DGS_NDT_DIRECT7>(h, L, grid, leaf_pow2); break;
+      case DGS_NDT_DIRECT1: launch_strict_rows<DGS_NDT_DIRECT1>(h, L, grid, leaf_pow2); break;
+      case DGS_NDT_DIRECT26: launch_strict_rows<DGS_NDT_DIRECT26>(h, L, grid, leaf_pow2); break;
+      case DGS_NDT_KDTREE: launch_strict_rows<DGS_NDT_KDTREE>(h, L, grid, leaf_pow2); break;
+      default: launch_strict_rows<DGS_NDT_DIRECT7>(h, L, grid, leaf_pow2); break;
     }
-    if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL)
-      hipLaunchKernelGGL(ndt_strict_seqsum_kernel, dim3(L.n_pairs), dim3(kWave), 0, h->stream, h->pairs.ptr, h->src_sizes.ptr, h->strict_rows.ptr, L.max_n,
-                         h->strict_totals.ptr);
-    // (order 1: the rows are summed by ndt_solve_kernel itself)
+    prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
+    return;
+  }
+  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM) {
+    switch (h->consts.search_method) {
+      case DGS_NDT_DIRECT1: launch_strict_sums<DGS_NDT_DIRECT1>(h, L, grid, leaf_pow2, launch, hd); break;
+      case DGS_NDT_DIRECT26: launch_strict_sums<DGS_NDT_DIRECT26>(h, L, grid, leaf_pow2, launch, hd); break;
+      case DGS_NDT_KDTREE: launch_strict_sums<DGS_NDT_KDTREE>(h, L, grid, leaf_pow2, launch, hd); break;
+      default: launch_strict_sums<DGS_NDT_DIRECT7>(h, L, grid, leaf_pow2, launch, hd); break;
+    }
     prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
     return;
   }
@@ -1634,7 +1880,7 @@ static void choose_queue(dgs_handle* h, NdtLaunch& L) {
 
 // Uploads pointers / sizes / initial poses, runs init, returns the launch shape.
 static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_host, const int* sizes_host, const float* guesses16,
-                     const double* probe_p6, NdtLaunch* launch_out, bool use_queue = false) {
+                     const double* probe_p6, NdtLaunch* launch_out, bool use_queue = false, int probe_kind = 1) {
   hipStream_t st = h->stream;
   fill_consts(h);
   int max_n = 0;
@@ -1655,8 +1901,9 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
   DGS_HIP_TRY(h, h->src_sizes.reserve(n_pairs));
   DGS_HIP_TRY(h, h->partials.reserve((size_t)n_pairs * L.cap_blocks * (h->consts.strict_order ? kStrictPad : kAccumPad)));
   if (h->consts.strict_order) DGS_HIP_TRY(h, h->strict_totals.reserve((size_t)n_pairs * kStrictPad));
-  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) DGS_HIP_TRY(h, h->strict_rows.reserve((size_t)n_pairs * kStrictAccum * L.max_n));
+  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) DGS_HIP_TRY(h, h->strict_rows.reserve((size_t)n_pairs * strict_rows_pair_stride(h, L)));
   DGS_HIP_TRY(h, h->pair_blocks.reserve(n_pairs));
+  if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM) DGS_HIP_TRY(h, hipMemsetAsync(h->pair_blocks.ptr, 0, sizeof(int) * n_pairs, st));   // "rows present" marks of the unfused upstream order
   DGS_HIP_TRY(h, h->done_counter.reserve(16));
   const size_t off_init = 256;
   const size_t off_ptr = off_init + sizeof(NdtInit) * n_pairs;
@@ -1674,7 +1921,16 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
       for (int k = 0; k < 6; k++) hin[i].p0[k] = probe_p6[k];
     } else {
       float e[3];
-      euler_angles_012(G, e);
+      if (h->prm.ndt_guess_rotation_polar) {   // eig_transformation.rotation().eulerAngles(0, 1, 2): Affine3f::rotation() is the polar factor
+        float R[9], Gp[16];
+        affine_rotation_f32(G, R);
+        std::memcpy(Gp, G, sizeof(Gp));
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++) Gp[c * 4 + r] = R[r * 3 + c];
+        euler_angles_012(Gp, e);
+      } else {
+        euler_angles_012(G, e);
+      }
       hin[i].p0[0] = G[12]; hin[i].p0[1] = G[13]; hin[i].p0[2] = G[14];
       hin[i].p0[3] = e[0]; hin[i].p0[4] = e[1]; hin[i].p0[5] = e[2];
     }
@@ -1687,7 +1943,7 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
   DGS_HIP_TRY(h, h->inits.reserve((stage_bytes + sizeof(NdtInit) - 1) / sizeof(NdtInit)));
   DGS_HIP_TRY(h, hipMemcpyAsync(h->inits.ptr, hin, stage_bytes, hipMemcpyHostToDevice, st));
   const char* dstage = reinterpret_cast<const char*>(h->inits.ptr);
-  hipLaunchKernelGGL(ndt_init_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->pairs.ptr, h->inits.ptr, n_pairs, h->consts, probe_p6 ? 1 : 0,
+  hipLaunchKernelGGL(ndt_init_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, st, h->pairs.ptr, h->inits.ptr, n_pairs, h->consts, probe_p6 ? probe_kind : 0,
                      h->done_counter.ptr, reinterpret_cast<const float4* const*>(dstage + (off_ptr - off_init)),
                      reinterpret_cast<const int*>(dstage + (off_size - off_init)), h->src_ptrs.ptr, h->src_sizes.ptr,
                      L.queue_workers > 0 ? h->ndt_queue.ptr : nullptr, L.queue_workers > 0 ? ndt_queue_slices(0, L.queue_base, L.cap_blocks) : 0,
@@ -1763,7 +2019,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   volatile int* flags = reinterpret_cast<volatile int*>(h->pinned);  // [0], [1]: done counts of alternating chunks
   flags[0] = flags[1] = 0;
   if (ensure_poll_events(h) != DGS_OK) return DGS_ERR_HIP;
-  const bool fused_flags = h->ndt_fused && h->consts.strict_order == DGS_NDT_ORDER_FAST;
+  const bool fused_flags = h->ndt_fused && h->consts.strict_order != DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL;   // the default order and the upstream order close inside the launch
   if (fused_flags) {   // fused launches: every pair has a "finished" flag in pinned host memory that its closing workgroup sets
     if (h->done_flags_cap < n_pairs) {
       if (h->done_flags) (void)hipHostFree(h->done_flags);
@@ -1779,7 +2035,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   const long max_evals = (long)(h->prm.maximum_iterations + 3) * per_iter + 2;
   const int chunk = 4;  // (derivatives, solve) launches between two looks at the done counter
   long queued = 0;
-  const bool fused = h->ndt_fused && h->consts.strict_order == DGS_NDT_ORDER_FAST;
+  const bool fused = fused_flags;
   int launch_no = 0;
   // DGS_NDT_SCHEDULE=1 (tests): every launch cuts the pairs into the slices the queue kernel would give that round, so that the two
   // paths sum the same partitions and can be compared bit for bit
@@ -1796,11 +2052,18 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
         Lr.total_blocks = n_pairs * Lr.cap_blocks;
       }
       round_no++;
+      const bool two_kinds = h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM && h->consts.hessian_double && !(strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25));   // ndt_strict.h, lane-per-point kernels: kinds 0 / 1, then kind 2
       if (fused) {
-        launch_derivatives(h, Lr, launch_no++);
+        launch_derivatives(h, Lr, launch_no);
+        if (two_kinds) launch_derivatives(h, Lr, launch_no, true);   // same round number: NdtPair::serve
+        launch_no++;
       } else {
         launch_derivatives(h, Lr);
         launch_solve(h, Lr);
+        if (two_kinds) {
+          launch_derivatives(h, Lr, -1, true);
+          launch_solve(h, Lr);
+        }
       }
     }
     queued += launches;
@@ -1921,7 +2184,7 @@ int ndt_trajectory(dgs_handle* h, int pair, double* out, int* len) {
 }
 
 // Test hook: one computeDerivatives evaluation on the device.
-int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36) {
+int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, double* g6, double* H36, int kind) {
   hipStream_t st = h->stream;
   NdtLaunch L{};
   const float4* src = h->src->pts.ptr;
@@ -1943,9 +2206,9 @@ int ndt_probe(dgs_handle* h, const double* p6, const float* T16, double* score, 
     T[10] = mul(cx, cy); T[14] = (float)p6[2];
     T[3] = T[7] = T[11] = 0.f; T[15] = 1.f;
   }
-  int rc = ndt_setup(h, 1, &src, &n, T, p6, &L);
+  int rc = ndt_setup(h, 1, &src, &n, T, p6, &L, false, kind);
   if (rc != DGS_OK) return rc;
-  launch_derivatives(h, L);
+  launch_derivatives(h, L, -1, kind == 2);
   launch_solve(h, L);
   char* base = reinterpret_cast<char*>(h->pinned);
   NdtPair* hp = reinterpret_cast<NdtPair*>(base + ((h->pinned_bytes - sizeof(NdtPair) - 64) & ~(size_t)63));

@@ -1,0 +1,599 @@
+// ndt_strict_order = 1 (UPSTREAM): computeDerivatives / updateDerivatives in upstream's own operation order, as ONE launch per
+// evaluation (derivatives + the pair's optimiser step in its closing workgroup).  Included by ndt_align.hip below the optimiser.
+//
+// What the mode promises (include/dgs_reg.h): every FLOAT operation of upstream's per-voxel update -- the CPU
+// checker states the same sequence -- individually rounded, in upstream's order; the float increments are
+// converted and added to DOUBLE sums.  Upstream adds them to a per-point total first and sums the points' totals in index order; here
+// every increment goes straight into the thread's running double sum, the threads' sums are added in a fixed order per workgroup, the
+// workgroups' rows in slice order.  A sum of <= 27 float increments is exact in double unless their exponents differ by more than
+// 29 bits, so the only difference to a CPU run is the association of the double additions (~1e-14 relative per evaluation) --
+// ndt_strict_order = 2 removes that too.
+//
+// Round 4 rewrite of round 2's validation kernel (which kept a point's 43 double totals AND the thread's 43 double totals in
+// registers -- 256 VGPRs, spills, 98 us per launch -- and left the optimiser to a second launch with a serial SVD):
+//   * voxel records as upstream's floats (VoxelStrictRec: the nine float(icov) entries are made once per target, not per visit);
+//   * one set of double accumulators per thread, a point's voxels visited through a per-lane list of its VALID slots (a wave runs as
+//     many rounds as its fullest point has voxels, not as many as there are slots with any taker);
+//   * score + gradient evaluations (More-Thuente trials) skip the Hessian code altogether (wave-uniform branch);
+//   * the closing workgroup (ticket hand-off as in the default order's fused kernel, common.h) sums the rows and advances the optimiser,
+//     with Eigen's two-sided JacobiSVD laid out across the wave (solve6.h);
+//   * evaluation kind 2: PCL's double-precision computeHessian / updateHessian pass (dgs_params.ndt_hessian_recompute_double).
+// (no namespace of its own: included inside namespace dgs)
+
+// exp(double) as the CPU checker states it: the fixed sequence of det_expf without the rounding to float, the
+// scaling by 2^k split in two so that subnormal results round once.
+__device__ __forceinline__ double det_exp(double x) {
+#pragma clang fp contract(off)
+  if (x != x) return x;
+  if (x < -746.0) return 0.0;
+  if (x > 710.0) return __builtin_inf();
+  const double kd = floor(x * 1.4426950408889634 + 0.5);
+  const double r = (x - kd * 0x1.62e42fefa38p-1) - kd * 0x1.ef35793c7673p-45;
+  double p = 1.0 / 6227020800.0;
+  p = p * r + 1.0 / 479001600.0;
+  p = p * r + 1.0 / 39916800.0;
+  p = p * r + 1.0 / 3628800.0;
+  p = p * r + 1.0 / 362880.0;
+  p = p * r + 1.0 / 40320.0;
+  p = p * r + 1.0 / 5040.0;
+  p = p * r + 1.0 / 720.0;
+  p = p * r + 1.0 / 120.0;
+  p = p * r + 1.0 / 24.0;
+  p = p * r + 1.0 / 6.0;
+  p = p * r + 0.5;
+  p = p * r + 1.0;
+  p = p * r + 1.0;
+  const long long k = (long long)kd;
+  const long long k1 = k / 2, k2 = k - k1;
+  const double s1 = __longlong_as_double((k1 + 1023) << 52), s2 = __longlong_as_double((k2 + 1023) << 52);
+  return (p * s1) * s2;
+}
+
+// Valid neighbour voxels of a transformed point, in upstream's visiting order: bit k of the result = slot k holds a voxel (vids[k]).
+template <int SEARCH>
+__device__ __forceinline__ unsigned strict_neighbourhood(const float (&xt)[3], const VoxelGrid& g, const int leaf_pow2, int (&vids)[Offsets<SEARCH>::N]) {
+  constexpr int NB = Offsets<SEARCH>::N;
+  const int c0 = (int)floorf(leaf_pow2 ? xt[0] * g.inv_leaf : xt[0] / g.leaf);
+  const int c1 = (int)floorf(leaf_pow2 ? xt[1] * g.inv_leaf : xt[1] / g.leaf);
+  const int c2 = (int)floorf(leaf_pow2 ? xt[2] * g.inv_leaf : xt[2] / g.leaf);
+  unsigned mask = 0;
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    int dx, dy, dz;
+    neighbour_offset<SEARCH>(k, dx, dy, dz);
+    const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
+    const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
+    vids[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+  }
+  if (SEARCH == DGS_NDT_KDTREE) {
+    const float r2 = g.leaf * g.leaf;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      if (vids[k] < 0) continue;
+      const float4 ce = g.centroid[vids[k]];
+      const float ex = ce.x - xt[0], ey = ce.y - xt[1], ez = ce.z - xt[2];
+      if (!(ex * ex + ey * ey + ez * ez < r2)) vids[k] = -1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++) mask |= (vids[k] >= 0) ? (1u << k) : 0u;
+  return mask;
+}
+
+template <int NB>
+__device__ __forceinline__ int strict_pick(const int (&vids)[NB], const int k) {   // vids stays in registers: a chain of selects, not scratch
+  int vid = vids[0];
+#pragma unroll
+  for (int j = 1; j < NB; j++) vid = (k == j) ? vids[j] : vid;
+  return vid;
+}
+
+// ---- kinds 0 / 1: updateDerivatives in float for ONE (point, voxel) item; acc = [score, g 0..5, H 0..35 row-major].
+// xt: the transformed point; xj / xh: the point's 8 + 15 products with the angle tables (computePointDerivatives).
+template <bool NEED_H>
+__device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&xj)[8], const float (&xh)[15], const VoxelStrictRec* __restrict__ rec,
+                                            const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
+  const float pg13 = xj[0], pg23 = xj[1];
+  const float pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
+  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);
+  const float4 ra = r4[0], rb = r4[1], rc = r4[2], rd = r4[3];
+  const double m0 = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x)), m1 = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z)),
+               m2 = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
+  const float q0 = (float)((double)xt[0] - m0), q1 = (float)((double)xt[1] - m1), q2 = (float)((double)xt[2] - m2);
+  const float C[3][3] = {{rb.z, rb.w, rc.x}, {rc.y, rc.z, rc.w}, {rd.x, rd.y, rd.z}};
+  float qC[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) qC[c] = q0 * C[0][c] + q1 * C[1][c] + q2 * C[2][c];
+  float e = det_expf(-gd2 * (q0 * qC[0] + q1 * qC[1] + q2 * qC[2]) * 0.5f);
+  const float score_inc = (float)(-gauss_d1 * (double)e);
+  e = gd2 * e;
+  if (e > 1 || e < 0 || e != e) return;
+  e = (float)((double)e * gauss_d1);
+  // C * point gradient: columns 0..2 are C itself (unit columns), column 3 has a zero first factor
+  float cPG[3][3];   // columns 3, 4, 5
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    cPG[r][0] = C[r][1] * pg13 + C[r][2] * pg23;
+    cPG[r][1] = C[r][0] * pg4[0] + C[r][1] * pg4[1] + C[r][2] * pg4[2];
+    cPG[r][2] = C[r][0] * pg5[0] + C[r][1] * pg5[1] + C[r][2] * pg5[2];
+  }
+  float g6[6];
+  g6[0] = qC[0]; g6[1] = qC[1]; g6[2] = qC[2];   // q^T (C * unit column) is q^T C: the same operations
+#pragma unroll
+  for (int c = 0; c < 3; c++) g6[3 + c] = q0 * cPG[0][c] + q1 * cPG[1][c] + q2 * cPG[2][c];
+#pragma unroll
+  for (int c = 0; c < 6; c++) acc[1 + c] += (double)(e * g6[c]);
+  if (NEED_H) {
+    // x^T C H for the six distinct vectors: a = (0, xh0, xh1) b = (0, xh2, xh3) c = (0, xh4, xh5) d = xh6..8 e = xh9..11 f = xh12..14
+    float xch[6];
+    xch[0] = qC[1] * xh[0] + qC[2] * xh[1];
+    xch[1] = qC[1] * xh[2] + qC[2] * xh[3];
+    xch[2] = qC[1] * xh[4] + qC[2] * xh[5];
+    xch[3] = qC[0] * xh[6] + qC[1] * xh[7] + qC[2] * xh[8];
+    xch[4] = qC[0] * xh[9] + qC[1] * xh[10] + qC[2] * xh[11];
+    xch[5] = qC[0] * xh[12] + qC[1] * xh[13] + qC[2] * xh[14];
+    // full C * J (3 x 6) as a lookup: column i < 3 -> C[r][i], else cPG[r][i - 3]
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const float ng = -gd2 * g6[i];
+      const float cj0 = (i < 3) ? C[0][i < 3 ? i : 0] : cPG[0][i < 3 ? 0 : i - 3];
+      const float cj1 = (i < 3) ? C[1][i < 3 ? i : 0] : cPG[1][i < 3 ? 0 : i - 3];
+      const float cj2 = (i < 3) ? C[2][i < 3 ? i : 0] : cPG[2][i < 3 ? 0 : i - 3];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float t = ng * g6[j];
+        if (i >= 3 && j >= 3) {
+          const int lo = (i < j ? i : j) - 3, hi = (i < j ? j : i) - 3;
+          t = t + xch[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+        }
+        // J_j^T (C J_i): column j of J is a unit vector for j < 3 and has a zero first entry for j == 3
+        const float pcp = (j == 0) ? cj0 : (j == 1) ? cj1 : (j == 2) ? cj2 : (j == 3) ? (pg13 * cj1 + pg23 * cj2)
+                        : (j == 4) ? (pg4[0] * cj0 + pg4[1] * cj1 + pg4[2] * cj2) : (pg5[0] * cj0 + pg5[1] * cj1 + pg5[2] * cj2);
+        acc[7 + i * 6 + j] += (double)(e * (t + pcp));
+      }
+    }
+  }
+  acc[0] += (double)score_inc;
+}
+
+// the point's products with the float angle tables (computePointDerivatives)
+template <bool NEED_H>
+__device__ __forceinline__ void strict_point_tables(const float4 x, const NdtPair& st, float (&xj)[8], float (&xh)[15]) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) xj[i] = st.jang[i][0] * x.x + st.jang[i][1] * x.y + st.jang[i][2] * x.z;
+  if (NEED_H) {
+#pragma unroll
+    for (int i = 0; i < 15; i++) xh[i] = st.hang[i][0] * x.x + st.hang[i][1] * x.y + st.hang[i][2] * x.z;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 15; i++) xh[i] = 0.f;
+  }
+}
+
+// one point, its valid voxels one after the other (a wave runs as many rounds as its fullest point has voxels)
+template <int SEARCH, bool NEED_H>
+__device__ __forceinline__ void strict_point(const float4 x, const float (&xt)[3], const int (&vids)[Offsets<SEARCH>::N], unsigned mask, const NdtPair& st,
+                                             const VoxelStrictRec* __restrict__ vs, const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
+  float xj[8], xh[15];
+  strict_point_tables<NEED_H>(x, st, xj, xh);
+  while (mask) {
+    const int k = __ffs(mask) - 1;
+    mask &= mask - 1u;
+    strict_item<NEED_H>(xt, xj, xh, vs + strict_pick(vids, k), gauss_d1, gd2, acc);
+  }
+}
+
+// ---- kind 2: computeHessian / updateHessian in PCL's double form, ONE (point, voxel) item.
+// xj / xh: the point's products with the DOUBLE angle vectors.  Returns false when the voxel's weight fails upstream's test.
+// ROWS = false: the 36 terms are added to acc[7 ..]; ROWS = true (ndt_strict_order 2): written to rows[entry * row_stride].
+template <bool ROWS>
+__device__ __forceinline__ bool strict_item_hd(const float (&xt)[3], const double (&xj)[8], const double (&xh)[15], const double* __restrict__ rec,
+                                               const double gauss_d1, const double gauss_d2, double (&acc)[kStrictAccum], double* __restrict__ rows, const size_t row_stride) {
+  const double pg13 = xj[0], pg23 = xj[1];
+  const double pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
+  double q[3], C[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) q[r] = (double)xt[r] - rec[r];   // mean[3], icov[9] row-major
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) C[r][c] = rec[3 + r * 3 + c];
+  double Cq[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) Cq[r] = C[r][0] * q[0] + C[r][1] * q[1] + C[r][2] * q[2];
+  double e = gauss_d2 * det_exp(-gauss_d2 * (q[0] * Cq[0] + q[1] * Cq[1] + q[2] * Cq[2]) / 2);
+  if (e > 1 || e < 0 || e != e) return false;
+  e *= gauss_d1;
+  // x_trans . (c_inv * point_hessian block) for the six distinct vectors a = (0, xh0, xh1) b c d = xh6..8 e f
+  double xch[6];
+#pragma unroll
+  for (int v = 0; v < 6; v++) {
+    double Ch[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      Ch[r] = (v < 3) ? (C[r][1] * xh[v < 3 ? 2 * v : 0] + C[r][2] * xh[v < 3 ? 2 * v + 1 : 0])
+                      : (C[r][0] * xh[v < 3 ? 0 : 3 * v - 3] + C[r][1] * xh[v < 3 ? 0 : 3 * v - 2] + C[r][2] * xh[v < 3 ? 0 : 3 * v - 1]);
+    xch[v] = q[0] * Ch[0] + q[1] * Ch[1] + q[2] * Ch[2];
+  }
+  // cov_dxd_pi = c_inv * point_gradient.col(i): column i of C for i < 3
+  double cd[6][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    cd[0][r] = C[r][0]; cd[1][r] = C[r][1]; cd[2][r] = C[r][2];
+    cd[3][r] = C[r][1] * pg13 + C[r][2] * pg23;
+    cd[4][r] = C[r][0] * pg4[0] + C[r][1] * pg4[1] + C[r][2] * pg4[2];
+    cd[5][r] = C[r][0] * pg5[0] + C[r][1] * pg5[1] + C[r][2] * pg5[2];
+  }
+  double A[6];   // x_trans . (c_inv * point_gradient.col(i))
+#pragma unroll
+  for (int i = 0; i < 6; i++) A[i] = q[0] * cd[i][0] + q[1] * cd[i][1] + q[2] * cd[i][2];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const double nA = -gauss_d2 * A[i];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double t = nA * A[j];
+      if (i >= 3 && j >= 3) {
+        const int lo = (i < j ? i : j) - 3, hi = (i < j ? j : i) - 3;
+        t = t + xch[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+      }
+      const double D = (j < 3) ? cd[i][j < 3 ? j : 0] : (j == 3) ? (pg13 * cd[i][1] + pg23 * cd[i][2])
+                     : (j == 4) ? (pg4[0] * cd[i][0] + pg4[1] * cd[i][1] + pg4[2] * cd[i][2]) : (pg5[0] * cd[i][0] + pg5[1] * cd[i][1] + pg5[2] * cd[i][2]);
+      const double term = e * (t + D);
+      if (ROWS) rows[(size_t)(i * 6 + j) * row_stride] = term;
+      else acc[7 + i * 6 + j] += term;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ void strict_point_tables_hd(const float4 xf, const NdtPair& st, double (&xj)[8], double (&xh)[15]) {
+  const double x[3] = {(double)xf.x, (double)xf.y, (double)xf.z};
+#pragma unroll
+  for (int i = 0; i < 8; i++) xj[i] = x[0] * st.jang_d[i][0] + x[1] * st.jang_d[i][1] + x[2] * st.jang_d[i][2];
+#pragma unroll
+  for (int i = 0; i < 15; i++) xh[i] = x[0] * st.hang_d[i][0] + x[1] * st.hang_d[i][1] + x[2] * st.hang_d[i][2];
+}
+
+// One point.  ROWS = true: every slot is visited and written -- zeros where a slot holds no voxel or the voxel's weight fails upstream's
+// test (adding +0.0 changes nothing) -- entry-major: rows[entry * row_stride + slot k of this point].
+template <int SEARCH, bool ROWS>
+__device__ __forceinline__ void strict_point_hd(const float4 xf, const float (&xt)[3], const int (&vids)[Offsets<SEARCH>::N], const unsigned mask_in, const NdtPair& st,
+                                                const double* __restrict__ vtab, const double gauss_d1, const double gauss_d2, double (&acc)[kStrictAccum],
+                                                double* __restrict__ rows, const size_t row_stride) {
+  constexpr int NB = Offsets<SEARCH>::N;
+  double xj[8], xh[15];
+  strict_point_tables_hd(xf, st, xj, xh);
+  unsigned mask = ROWS ? ((NB >= 32) ? 0xFFFFFFFFu : ((1u << NB) - 1u)) : mask_in;
+  while (mask) {
+    const int k = __ffs(mask) - 1;
+    mask &= mask - 1u;
+    bool ok = ((mask_in >> k) & 1u) != 0;
+    if (ok) ok = strict_item_hd<ROWS>(xt, xj, xh, vtab + (size_t)strict_pick(vids, k) * 12, gauss_d1, gauss_d2, acc, ROWS ? rows + k : nullptr, row_stride);
+    if (ROWS && !ok) {
+      for (int en = 0; en < 36; en++) rows[(size_t)en * row_stride + k] = 0.0;
+    }
+  }
+}
+
+// Block reduction of the 43 per-thread totals into one row of kStrictPad doubles (ncol = 7 for a score + gradient evaluation): every wave
+// transposes through LDS, 11 values at a time (lane l stores value k at row k, then lane k adds the 64 entries of row k in lane order),
+// the four waves' sums are added in wave order.  Same construction as ndt_block_row, same reason: a DPP / shuffle butterfly over 43
+// doubles costs ~1,500 wave-instructions.
+constexpr int kStrictRowScratch = 11 * 65;   // doubles of per-wave transposition scratch
+template <bool COHERENT, bool OWN_SCRATCH = true>
+__device__ __forceinline__ void strict_block_row(const double (&acc)[kStrictAccum], const int ncol, double* __restrict__ row_of_slice, double* wave_scratch = nullptr) {
+  constexpr int CH = 11, RS = 65, NCH = 4;
+  __shared__ double tr[OWN_SCRATCH ? kBlock / kWave : 1][OWN_SCRATCH ? CH * RS : 1];
+  __shared__ double sm[kBlock / kWave][kStrictPad];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* my = OWN_SCRATCH ? tr[wave] : wave_scratch;   // !OWN_SCRATCH: this wave's own LDS region (>= kStrictRowScratch doubles), free by now
+#pragma unroll
+  for (int h = 0; h < NCH; h++) {
+    if (h * CH >= ncol) break;   // wave-uniform
+#pragma unroll
+    for (int k = 0; k < CH; k++) my[k * RS + lane] = (h * CH + k < kStrictAccum) ? acc[h * CH + k < kStrictAccum ? h * CH + k : 0] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    if (lane < CH) {
+      double v = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 64; j++) v += my[lane * RS + j];
+      sm[wave][h * CH + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+  __syncthreads();
+  if (threadIdx.x < kStrictPad) {
+    double v = 0.0;
+    if ((int)threadIdx.x < ncol) v = ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + sm[2][threadIdx.x]) + sm[3][threadIdx.x];
+    double* row = row_of_slice + threadIdx.x;
+    if (COHERENT) handoff_store_row(row, v);
+    else *row = v;
+  }
+}
+
+// Sums a pair's rows in slice order and advances its optimiser by one evaluation (one whole workgroup; launch >= 0: inside the fused
+// launch, rows read with the hand-off's coherent loads, the pair leaves through last_launch + its host flag).
+// HD / ONE_KERNEL: which kernel of the round runs this closing -- see NdtPair::serve.  ONE_KERNEL (ndt_strict3_kernel): every evaluation
+// kind is served by the round's only launch.
+template <bool HD, bool ONE_KERNEL = false>
+__device__ __forceinline__ void ndt_close_strict(NdtPair* st, const double* rows_of_pair, const int blocks_per_pair, const NdtConsts& c, int* done_flag, const int launch) {
+  __shared__ NdtSolver s_lds;
+  NdtSolver& s = s_lds;
+  static_assert(sizeof(NdtSolver) % 8 == 0 && sizeof(NdtSolver) / 8 <= kBlock, "state words");
+  constexpr int kWords = (int)(sizeof(NdtSolver) / 8);
+  double word = 0.0;
+  if (threadIdx.x < kWords) word = reinterpret_cast<const double*>(&st->s)[threadIdx.x];
+  const int kind = st->need_hessian;
+  __shared__ double tot[kStrictPad];
+  constexpr int G = kBlock / kStrictPad;   // 5 groups of 48 columns; threads 240.. idle
+  __shared__ double sm[G][kStrictPad];
+  const int col = threadIdx.x % kStrictPad, grp = threadIdx.x / kStrictPad;
+  if (grp < G) {
+    double v = 0.0;
+    for (int b0 = grp; b0 < blocks_per_pair; b0 += 4 * G) {
+      double r[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int b = b0 + k * G;
+        const double* ptr = rows_of_pair + (size_t)min(b, blocks_per_pair - 1) * kStrictPad + col;
+        const double x = (launch >= 0) ? handoff_load_row(ptr) : *ptr;
+        r[k] = (b < blocks_per_pair) ? x : 0.0;
+      }
+      v = (((v + r[0]) + r[1]) + r[2]) + r[3];
+    }
+    sm[grp][col] = v;
+  }
+  if (threadIdx.x < kWords) reinterpret_cast<double*>(&s_lds)[threadIdx.x] = word;
+  __syncthreads();
+  if (threadIdx.x < kStrictPad) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < G; k++) t += sm[k][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  const bool writer = threadIdx.x == 0;
+  {
+    const int t = threadIdx.x;
+    if (t < 36) {
+      if (kind) s.hess[t] = tot[7 + t];   // upstream's full 6 x 6 (not exactly symmetric)
+    } else if (t < 42) {
+      if (kind != 2) s.grad[t - 36] = tot[1 + t - 36];
+    } else if (t == 42) {
+      if (kind != 2) s.score = tot[0];    // computeHessian alone (kind 2) leaves score and gradient as the last trial left them
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+  ndt_advance<false, false, true>(st, st, s, c, writer);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  for (int w = threadIdx.x; w < kWords; w += kWave) reinterpret_cast<double*>(&st->s)[w] = reinterpret_cast<const double*>(&s_lds)[w];
+  if (writer) {
+    if (s.phase == PH_DONE) {
+      st->active = 0;
+      if (launch >= 0) {
+        st->last_launch = launch;
+        __hip_atomic_store(done_flag, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        atomicAdd(done_flag, 1);
+      }
+    } else if (launch >= 0) {
+      // which kernel of which round serves the evaluation just queued (NdtPair::serve); `launch` is the round number
+      if (ONE_KERNEL) st->serve[0] = launch + 1;
+      else if (st->need_hessian == 2) st->serve[1] = HD ? launch + 1 : launch;   // the double computeHessian kernel of this round follows this launch
+      else st->serve[0] = launch + 1;
+    }
+  }
+}
+
+// FUSED: round number `launch` of the align; the workgroup that takes the pair's last ticket closes the evaluation (ndt_close_strict).
+// Otherwise derivatives only, rows summed by ndt_solve_kernel (DGS_NDT_FUSED=0, the test hook).
+// HD = false: the pairs whose evaluation in flight is of kind 0 / 1 (updateDerivatives in float); HD = true: the pairs waiting for kind 2
+// (computeHessian in double).  Two instantiations, launched one behind the other in every round, because the double pass keeps ~130
+// registers of double tables next to the accumulators: in one kernel it pushed every path to 256 VGPRs and 87 spilled registers.  A pair
+// is served by exactly one of the two in a round -- or by both when the first one's closing asks for kind 2, which the second one then
+// evaluates in the same round (the kernel boundary orders it; results do not depend on it).
+template <int SEARCH, bool FUSED, bool HD>
+__global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes, NdtPair* __restrict__ pairs,
+                                                              const VoxelGrid g, const VoxelStrictRec* __restrict__ vs, const double* __restrict__ vtab,
+                                                              const double gauss_d1, const double gauss_d2, const int leaf_pow2, double* __restrict__ partials,
+                                                              const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks, const NdtConsts consts,
+                                                              int* __restrict__ done_flags, const int launch) {
+  int pair, slice, blocks_per_pair;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return FUSED ? (launch <= pairs[pi].serve[HD ? 1 : 0]) : (pairs[pi].active != 0 && (pairs[pi].need_hessian == 2) == HD); },
+                      pair, slice, blocks_per_pair)) return;
+  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
+  const NdtPair& st = pairs[pair];
+  const float4* __restrict__ src = src_ptrs[pair];
+  const int n = src_sizes[pair];
+  const int kind = HD ? 2 : st.need_hessian;   // 0: score + gradient, 1: + Hessian (float), 2: Hessian alone in double (computeHessian)
+  const float gd2 = (float)gauss_d2;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st.T[k];
+  double acc[kStrictAccum];
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) acc[k] = 0.0;
+  constexpr int NB = Offsets<SEARCH>::N;
+  for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
+    const float4 x = src[i];
+    float xt[3];
+    xt[0] = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
+    xt[1] = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
+    xt[2] = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
+    int vids[NB];
+    const unsigned mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
+    if (!mask) continue;
+    if (HD) strict_point_hd<SEARCH, false>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, nullptr, 0);
+    else if (kind == 1) strict_point<SEARCH, true>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc);
+    else strict_point<SEARCH, false>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc);
+  }
+  strict_block_row<FUSED>(acc, kind ? kStrictAccum : 7, partials + ((size_t)pair * cap_blocks + slice) * kStrictPad);
+  if (!FUSED) return;
+  __shared__ int s_last;
+  if (threadIdx.x < kStrictPad) handoff_drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, blocks_per_pair) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  ndt_close_strict<HD>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch);
+}
+
+// ================================================================================================ item-compacted kernel (v3)
+// The kernel above gives a lane a POINT and lets it walk the point's valid voxels: a wave runs as many rounds as its fullest point has
+// voxels (5.5-6 on scan data against 4.0 on average), and the double-precision computeHessian pass needs a kernel of its own because its
+// per-point double tables do not fit the register file next to the accumulators.  Here a lane gets an ITEM -- one (point, voxel) pair:
+//   * a wave takes a tile of its points (128, or 64 for the 27-slot searches and the double pass), lane = point: transform, neighbourhood,
+//     the point's products with the angle tables -> LDS, field-major ([field][slot]: conflict-free both ways); every valid (slot, voxel)
+//     is appended to the wave's item queue in LDS at a position made from ballots, so the order of the items -- and with it the order of
+//     every double addition -- is a function of the data alone;
+//   * then lane l of round r processes item 64 r + l: it reads its point's tables from LDS and the voxel's record from L2 and adds the
+//     item's float increments to ITS double accumulators.  Every round but the last of a tile has all 64 lanes busy.
+// Which thread adds which item differs from the kernel above, i.e. the association of the double sums differs once more (~1e-14); every
+// float operation is the same (the same strict_item / strict_item_hd).  All three evaluation kinds run in ONE launch per round.
+template <int SEARCH>
+struct StrictTile {
+  static constexpr int NB = Offsets<SEARCH>::N;
+  static constexpr int PTS = (NB <= 7) ? 128 : 64;   // points per wave and tile (float kinds)
+  static constexpr int PTS_HD = 64;                  // double pass: 23 doubles + 3 floats per point
+  static constexpr int kFields = 26;                 // xt[3], xj[8], xh[15]
+  static constexpr int kTableBytes = kFields * PTS * 4 > (23 * 8 + 3 * 4) * PTS_HD ? kFields * PTS * 4 : (23 * 8 + 3 * 4) * PTS_HD;
+  static constexpr int kQueue = PTS * NB;            // items of a tile at most
+};
+
+template <int SEARCH, bool FUSED>
+__global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes, NdtPair* __restrict__ pairs,
+                                                               const VoxelGrid g, const VoxelStrictRec* __restrict__ vs, const double* __restrict__ vtab,
+                                                               const double gauss_d1, const double gauss_d2, const int leaf_pow2, double* __restrict__ partials,
+                                                               const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks, const NdtConsts consts,
+                                                               int* __restrict__ done_flags, const int launch) {
+  using TL = StrictTile<SEARCH>;
+  constexpr int NB = TL::NB;
+  int pair, slice, blocks_per_pair;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return FUSED ? (launch <= pairs[pi].serve[0]) : (pairs[pi].active != 0); }, pair, slice, blocks_per_pair)) return;
+  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
+  const NdtPair& st = pairs[pair];
+  const float4* __restrict__ src = src_ptrs[pair];
+  const int n = src_sizes[pair];
+  const int kind = st.need_hessian;
+  const float gd2 = (float)gauss_d2;
+  float T[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) T[k] = st.T[k];
+  double acc[kStrictAccum];
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) acc[k] = 0.0;
+
+  __shared__ __attribute__((aligned(16))) unsigned char s_tab[kBlock / kWave][TL::kTableBytes];
+  __shared__ unsigned s_queue[kBlock / kWave][TL::kQueue];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* tf = reinterpret_cast<float*>(s_tab[wave]);            // float kinds: [26][PTS]
+  double* td = reinterpret_cast<double*>(s_tab[wave]);          // double pass: [23][PTS_HD] doubles, then [3][PTS_HD] floats
+  float* tdx = reinterpret_cast<float*>(s_tab[wave] + 23 * 8 * TL::PTS_HD);
+  unsigned* queue = s_queue[wave];
+  const int pts = (kind == 2) ? TL::PTS_HD : TL::PTS;           // wave-uniform
+  const int subs = pts / 64;
+  const int stride = blocks_per_pair * kBlock;
+  // the wave's points: i = first + lane + sub * stride, tiles of `subs` strides
+  for (int first = slice * kBlock + wave * 64; first < n; first += subs * stride) {
+    int qn = 0;
+    for (int sub = 0; sub < subs; sub++) {
+      const int i = first + sub * stride + lane;
+      const int slot = sub * 64 + lane;
+      unsigned mask = 0;
+      int vids[NB];
+      if (i < n) {
+        const float4 x = src[i];
+        float xt[3];
+        xt[0] = affine_row_rn(T[0], T[1], T[2], T[3], x.x, x.y, x.z);
+        xt[1] = affine_row_rn(T[4], T[5], T[6], T[7], x.x, x.y, x.z);
+        xt[2] = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
+        mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
+        if (mask) {
+          if (kind == 2) {
+            double xj[8], xh[15];
+            strict_point_tables_hd(x, st, xj, xh);
+#pragma unroll
+            for (int f = 0; f < 8; f++) td[f * TL::PTS_HD + slot] = xj[f];
+#pragma unroll
+            for (int f = 0; f < 15; f++) td[(8 + f) * TL::PTS_HD + slot] = xh[f];
+#pragma unroll
+            for (int f = 0; f < 3; f++) tdx[f * TL::PTS_HD + slot] = xt[f];
+          } else {
+            float xj[8], xh[15];
+            if (kind == 1) strict_point_tables<true>(x, st, xj, xh);
+            else strict_point_tables<false>(x, st, xj, xh);
+#pragma unroll
+            for (int f = 0; f < 3; f++) tf[f * TL::PTS + slot] = xt[f];
+#pragma unroll
+            for (int f = 0; f < 8; f++) tf[(3 + f) * TL::PTS + slot] = xj[f];
+            if (kind == 1) {
+#pragma unroll
+              for (int f = 0; f < 15; f++) tf[(11 + f) * TL::PTS + slot] = xh[f];
+            }
+          }
+        }
+      }
+      // append this sub-tile's items, slot-major: positions from ballots
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const bool has = (mask >> k) & 1u;
+        const unsigned long long b = __ballot(has);
+        if (has) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u))] = ((unsigned)slot << 25) | (unsigned)vids[k];
+        qn += __popcll(b);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    // ---- the items, 64 at a time
+    for (int h = 0; h < qn; h += 64) {
+      const int idx = h + lane;
+      if (idx < qn) {
+        const unsigned entry = queue[idx];
+        const int slot = (int)(entry >> 25), vid = (int)(entry & 0x1FFFFFFu);
+        if (kind == 2) {
+          double xj[8], xh[15];
+          float xt[3];
+#pragma unroll
+          for (int f = 0; f < 8; f++) xj[f] = td[f * TL::PTS_HD + slot];
+#pragma unroll
+          for (int f = 0; f < 15; f++) xh[f] = td[(8 + f) * TL::PTS_HD + slot];
+#pragma unroll
+          for (int f = 0; f < 3; f++) xt[f] = tdx[f * TL::PTS_HD + slot];
+          (void)strict_item_hd<false>(xt, xj, xh, vtab + (size_t)vid * 12, gauss_d1, gauss_d2, acc, nullptr, 0);
+        } else {
+          float xt[3], xj[8], xh[15];
+#pragma unroll
+          for (int f = 0; f < 3; f++) xt[f] = tf[f * TL::PTS + slot];
+#pragma unroll
+          for (int f = 0; f < 8; f++) xj[f] = tf[(3 + f) * TL::PTS + slot];
+          if (kind == 1) {
+#pragma unroll
+            for (int f = 0; f < 15; f++) xh[f] = tf[(11 + f) * TL::PTS + slot];
+            strict_item<true>(xt, xj, xh, vs + vid, gauss_d1, gd2, acc);
+          } else {
+#pragma unroll
+            for (int f = 0; f < 15; f++) xh[f] = 0.f;
+            strict_item<false>(xt, xj, xh, vs + vid, gauss_d1, gd2, acc);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the next tile overwrites the tables and the queue (LDS operations of one wave stay in order)
+  }
+  static_assert(TL::kTableBytes >= kStrictRowScratch * 8, "the wave's table region doubles as its reduction scratch");
+  strict_block_row<FUSED, false>(acc, kind ? kStrictAccum : 7, partials + ((size_t)pair * cap_blocks + slice) * kStrictPad, td);
+  if (!FUSED) return;
+  __shared__ int s_last;
+  if (threadIdx.x < kStrictPad) handoff_drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, blocks_per_pair) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  ndt_close_strict<false, true>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch);
+}

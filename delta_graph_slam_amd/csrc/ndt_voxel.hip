@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __
                                                                 int* __restrict__ scalars, int min_points, double eig_mult,
                                                                 int* __restrict__ cell2vox, VoxelRec* __restrict__ vox,
                                                                 float4* __restrict__ centroid, double* __restrict__ dbg,
-                                                                int* __restrict__ vcount, int* __restrict__ vvalid) {
+                                                                int* __restrict__ vcount, int* __restrict__ vvalid, VoxelStrictRec* __restrict__ vstrict) {
 #pragma clang fp contract(off)  // the table is compared bit for bit with the CPU checker: every operation individually rounded
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int num_runs = scalars[0];
@@ -205,6 +205,13 @@ __global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __
     }
   }
   vox[r] = rec;
+  {
+    VoxelStrictRec sr;
+    sr.mean[0] = mean[0]; sr.mean[1] = mean[1]; sr.mean[2] = mean[2];
+    for (int k = 0; k < 9; k++) sr.C[k] = (float)d[3 + k];   // float(icov), what upstream's updateDerivatives casts per visit
+    sr.pad = 0.f;
+    vstrict[r] = sr;
+  }
   centroid[r] = make_float4(cf[0] / fn, cf[1] / fn, cf[2] / fn, valid ? 1.f : 0.f);
   vvalid[r] = valid ? 1 : 0;
   cell2vox[key] = valid ? r : -1;
@@ -473,6 +480,7 @@ int ndt_build_target(dgs_handle* h) {
   g.mul1 = g.div_b[0];
   g.mul2 = g.div_b[0] * g.div_b[1];
   h->grid_cells = dense_cells;
+  h->n_occupied_bound = n;
 
   // 3. buffers
   DGS_HIP_TRY(h, h->cell2vox.reserve((size_t)dense_cells));
@@ -487,6 +495,7 @@ int ndt_build_target(dgs_handle* h) {
   DGS_HIP_TRY(h, h->vox.reserve(n));
   DGS_HIP_TRY(h, h->vox_centroid.reserve(n));
   DGS_HIP_TRY(h, h->vox_dbg.reserve((size_t)n * 12));
+  DGS_HIP_TRY(h, h->vox_strict.reserve(n));
   DGS_HIP_TRY(h, h->vox_count.reserve(n));
   DGS_HIP_TRY(h, h->vox_valid.reserve(n));
   DGS_HIP_TRY(h, h->scratch_cloud.reserve(n));
@@ -517,7 +526,7 @@ int ndt_build_target(dgs_handle* h) {
   // 5. per-voxel statistics
   hipLaunchKernelGGL(voxel_finalize_kernel, dim3(nb), dim3(kBlock), 0, st, h->scratch_cloud.ptr, h->run_keys.ptr, h->run_counts.ptr,
                      h->run_offsets.ptr, h->dev_scalars.ptr, h->prm.ndt_min_points_per_voxel, h->prm.ndt_min_covar_eigvalue_mult,
-                     h->cell2vox.ptr, h->vox.ptr, h->vox_centroid.ptr, h->vox_dbg.ptr, h->vox_count.ptr, h->vox_valid.ptr);
+                     h->cell2vox.ptr, h->vox.ptr, h->vox_centroid.ptr, h->vox_dbg.ptr, h->vox_count.ptr, h->vox_valid.ptr, h->vox_strict.ptr);
   prof_end(h, DGS_K_NDT_VOXEL_BUILD, slot);
   DGS_HIP_TRY(h, hipGetLastError());
   g.cell2vox = h->cell2vox.ptr;

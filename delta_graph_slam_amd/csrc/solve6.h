@@ -206,6 +206,204 @@ __device__ __forceinline__ void svd_solve6_regs_dev(const double* A, const doubl
   }
 }
 
+// ---- Eigen::JacobiSVD<Matrix6d>(A, ComputeFullU | ComputeFullV).solve(b), lane-parallel (dgs_params.ndt_newton_solver = 1) --------
+// The operation sequence of the CPU checker's restatement of Eigen's two-sided Jacobi (steps 1-4 of JacobiSVD::compute, SVDBase::rank,
+// the solve), every operation individually rounded -- so the Newton step of the upstream evaluation orders comes out bit-identical --
+// but laid out across ONE wave instead of run by every lane:
+//   lanes 0..5   column j of the work matrix W,   lanes 8..13  column j of U,   lanes 16..21  column j of V     (six doubles each);
+//   the 2x2 block of a pair (p, q) reaches every lane through v_readlane; the rotation angles (three square roots, six divisions: one
+//   dependent chain) are computed by every lane alike; W <- J_left W is local to the W lanes (rows p, q of their columns); the three
+//   column rotations W J_right, U J_left, V J_right are ONE exchange of columns p <-> q inside each 8-lane group (lane ^ (p ^ q)) and
+//   three multiply-adds per entry, every group with its own (c, s).
+// A one-wave solve executes ~45 rotations of ~230 instructions (5 sweeps on the NDT Hessians) where rounds 2-3's one-sided Jacobi ran 60
+// sweeps of dot products on every lane (~85 k instructions, 95-190 us per Newton step).
+// Must be called by all 64 lanes of a wave with identical arguments; A row-major 6 x 6 and b in LDS or any memory; every lane receives x.
+template <int P, int Q>
+__device__ __forceinline__ void jsvd_pair(double (&col)[6], double& max_diag, bool& finished, const int grp, const int j) {
+#pragma clang fp contract(off)
+  const double kMin = DBL_MIN;
+  const double w_pq = readlane_f64(col[P], Q), w_qp = readlane_f64(col[Q], P);   // W(p, q) lives in column q, row p
+  const double pm = (2.0 * DBL_EPSILON) * max_diag;
+  const double threshold = kMin > pm ? kMin : pm;
+  if (!(fabs(w_pq) > threshold || fabs(w_qp) > threshold)) return;
+  finished = false;
+  // ---- real_2x2_jacobi_svd
+  double m00 = readlane_f64(col[P], P), m01 = w_pq, m10 = w_qp, m11 = readlane_f64(col[Q], Q);
+  const double t = m00 + m11, d = m10 - m01;
+  double r1c, r1s;
+  if (fabs(d) < kMin) { r1s = 0.0; r1c = 1.0; }
+  else {
+    const double u = t / d;
+    const double tmp = sqrt(1.0 + u * u);
+    r1s = 1.0 / tmp;
+    r1c = u / tmp;
+  }
+  if (!(r1c == 1.0 && r1s == 0.0)) {
+    const double x0 = m00, y0 = m10, x1 = m01, y1 = m11;
+    m00 = r1c * x0 + r1s * y0; m10 = -r1s * x0 + r1c * y0;
+    m01 = r1c * x1 + r1s * y1; m11 = -r1s * x1 + r1c * y1;
+  }
+  double jrc, jrs;
+  {
+    const double deno = 2.0 * fabs(m01);
+    if (deno < kMin) { jrc = 1.0; jrs = 0.0; }
+    else {
+      const double tau = (m00 - m11) / deno;
+      const double w = sqrt(tau * tau + 1.0);
+      const double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+      const double sign_t = tt > 0.0 ? 1.0 : -1.0;
+      const double nn = 1.0 / sqrt(tt * tt + 1.0);
+      jrs = -sign_t * (m01 / fabs(m01)) * fabs(tt) * nn;
+      jrc = nn;
+    }
+  }
+  const double jtc = jrc, jts = -jrs;
+  const double jlc = r1c * jtc - r1s * jts;
+  const double jls = r1c * jts + r1s * jtc;
+  const bool left_id = (jlc == 1.0 && jls == 0.0), right_id = (jrc == 1.0 && -jrs == 0.0);
+  // ---- W.applyOnTheLeft(p, q, j_left): rows p, q of every W column
+  if (grp == 0 && !left_id) {
+    const double xi = col[P], yi = col[Q];
+    col[P] = jlc * xi + jls * yi;
+    col[Q] = -jls * xi + jlc * yi;
+  }
+  // ---- the three column rotations: x' = c x + s y (column p), y' = -s x + c y (column q)
+  //      W, V: (c, s) = j_right.transpose() = (jrc, -jrs);   U: (c, s) = j_left
+  const double c = (grp == 1) ? jlc : jrc, s = (grp == 1) ? jls : -jrs;
+  const bool skip = (grp == 1) ? left_id : right_id;
+  const bool is_p = (j == P), is_q = (j == Q);
+  const double sg = is_p ? s : -s;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double other = __shfl_xor(col[k], P ^ Q, 64);
+    const double v = c * col[k] + sg * other;    // column p: c x + s y;   column q: c y + (-s) x = -s x + c y
+    col[k] = ((is_p || is_q) && !skip) ? v : col[k];
+  }
+  const double app = fabs(readlane_f64(col[P], P)), aqq = fabs(readlane_f64(col[Q], Q));
+  const double mx = app < aqq ? aqq : app;
+  if (max_diag < mx) max_diag = mx;
+}
+
+__device__ __forceinline__ void jsvd_solve6_wave(const double* A, const double* b, double* x, int* sweeps_out = nullptr) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int grp = min(lane >> 3, 2);           // 0: W, 1: U, 2: V (lanes 24.. mirror V lanes: idle copies)
+  const int j = lane & 7;                      // column; 6 and 7 hold zeros
+  const int jc = j < 6 ? j : 0;
+  // ---- step 1: scale = max |A|, W = A / scale, U = V = I
+  double col[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) col[k] = A[k * 6 + jc];
+  double amax = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { const double a = fabs(col[k]); if (a > amax) amax = a; }
+  double scale = 0.0;
+#pragma unroll
+  for (int l = 0; l < 6; l++) { const double a = readlane_f64(amax, l); if (a > scale) scale = a; }
+  if (scale == 0.0) scale = 1.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double w = col[k] / scale;
+    col[k] = (j >= 6) ? 0.0 : (grp == 0 ? w : (k == j ? 1.0 : 0.0));
+  }
+  // ---- step 2: sweeps
+  double dj = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) dj = (k == j) ? fabs(col[k]) : dj;
+  double max_diag = 0.0;
+#pragma unroll
+  for (int l = 0; l < 6; l++) { const double a = readlane_f64(dj, l); if (a > max_diag) max_diag = a; }
+  bool finished = false;
+  int sweeps = 0;
+  while (!finished && sweeps < 64) {
+    finished = true;
+    sweeps++;
+    jsvd_pair<1, 0>(col, max_diag, finished, grp, j);
+    jsvd_pair<2, 0>(col, max_diag, finished, grp, j);
+    jsvd_pair<2, 1>(col, max_diag, finished, grp, j);
+    jsvd_pair<3, 0>(col, max_diag, finished, grp, j);
+    jsvd_pair<3, 1>(col, max_diag, finished, grp, j);
+    jsvd_pair<3, 2>(col, max_diag, finished, grp, j);
+    jsvd_pair<4, 0>(col, max_diag, finished, grp, j);
+    jsvd_pair<4, 1>(col, max_diag, finished, grp, j);
+    jsvd_pair<4, 2>(col, max_diag, finished, grp, j);
+    jsvd_pair<4, 3>(col, max_diag, finished, grp, j);
+    jsvd_pair<5, 0>(col, max_diag, finished, grp, j);
+    jsvd_pair<5, 1>(col, max_diag, finished, grp, j);
+    jsvd_pair<5, 2>(col, max_diag, finished, grp, j);
+    jsvd_pair<5, 3>(col, max_diag, finished, grp, j);
+    jsvd_pair<5, 4>(col, max_diag, finished, grp, j);
+  }
+  if (sweeps_out) *sweeps_out = sweeps;
+  // ---- step 3: singular values |W_jj| * scale; U columns negated where W_jj < 0
+  double wjj = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) wjj = (k == j) ? col[k] : wjj;
+  wjj = __shfl(wjj, jc, 64);                   // every group: the diagonal entry of ITS column index, from the W lane
+  const double svj = fabs(wjj) * scale;
+  if (grp == 1 && wjj < 0.0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) col[k] = -col[k];
+  }
+  // ---- step 4: descending order (selection by the first maximum of the tail), kept as a permutation: sorted slot r <- column ord[r]
+  double sv[6];
+  int ord[6];
+#pragma unroll
+  for (int l = 0; l < 6; l++) { sv[l] = readlane_f64(svj, l); ord[l] = l; }
+  int nonzero = 6;
+  bool stop = false;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    int pos = i;
+    double best = sv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) if (sv[k] > best) { best = sv[k]; pos = k; }
+    if (!stop && best == 0.0) { nonzero = i; stop = true; }
+    if (!stop) {
+#pragma unroll
+      for (int k = i + 1; k < 6; k++)
+        if (k == pos) { const double ts = sv[i]; sv[i] = sv[k]; sv[k] = ts; const int to = ord[i]; ord[i] = ord[k]; ord[k] = to; }
+    }
+  }
+  // ---- rank and solve: tmp_r = (1 / s_r) (U(:, ord r) . b),  x = sum over r < rank, in sorted order, of V(:, ord r) tmp_r
+  const double pt = sv[0] * (6.0 * DBL_EPSILON);
+  const double premultiplied = pt > DBL_MIN ? pt : DBL_MIN;
+  int rank = 0;
+  {
+    int r = nonzero - 1;
+    bool going = true;
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+      if (going && k <= r) {
+        if (sv[k] < premultiplied) r = k - 1; else going = false;
+      }
+    }
+    rank = r + 1;
+  }
+  // U lane j: (1 / s_j) * (column . b), with s_j the singular value of column j (before sorting it is svj)
+  double ub = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) ub = (k == 0) ? col[k] * b[k] : ub + col[k] * b[k];
+  const double tj = (1.0 / svj) * ub;          // meaningful in U lanes
+  const double tv = __shfl(tj, 8 + jc, 64);    // V lane j receives tmp of column j
+  double prod[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) prod[k] = col[k] * tv;   // V lanes: V(k, j) * tmp_j
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    if (r < rank) {
+      const int src = 16 + ord[r];
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const double term = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(prod[i]), src), __builtin_amdgcn_readlane(__double2loint(prod[i]), src));
+        x[i] = (r == 0) ? term : x[i] + term;
+      }
+    }
+  }
+}
+
 // x = A^-1 b with the pseudo-inverse fallback Eigen's JacobiSVD::solve would give on a singular A (wave-uniform)
 __device__ __forceinline__ void solve6_wave(const double* A, const double* b, double* x) {
   double rc;

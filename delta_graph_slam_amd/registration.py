@@ -378,6 +378,13 @@ class Registration:
                                                    C.byref(s), g.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
         return s.value, g, H
 
+    def ndt_hessian_double(self, p):
+        """computeHessian in PCL's double form at pose p (dgs_ndt_hessian_double; upstream evaluation orders only)."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        H = np.zeros((6, 6))
+        self._check(self._lib.dgs_ndt_hessian_double(self._h, p.ctypes.data_as(C.c_void_p), H.ctypes.data_as(C.c_void_p)))
+        return H
+
     def gicp_covariances(self, which: str = "source", n: int | None = None):
         c = self.counts()   # the library writes one 3x3 per point of the cloud it holds: size the buffer from ITS count
         n = int(c["source_points"] if which == "source" else c["target_points"])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGS_ABI_VERSION 4
+#define DGS_ABI_VERSION 5
 
 typedef struct dgs_handle dgs_handle;
 typedef struct dgs_cloud dgs_cloud; /* a cloud resident in HBM together with its NN index / covariances (see below) */
@@ -118,6 +118,17 @@ typedef struct dgs_params {
   /* FAST_VGICP (uses the gicp_* fields above except gicp_max_correspondence_distance: VGICP has no distance gate) */
   int32_t vgicp_search_method;             /* default DGS_VGICP_DIRECT1 (FastVGICP constructor) */
   double vgicp_resolution;                 /* setResolution(reg_resolution), factory default 1.0 (registrations.cpp:52) */
+  /* ---- three details of un-vendored upstream code behind named switches (ABI 5; [UPSTREAM-RECALL]).  Each
+   * defaults to what the published upstream source does as far as it can be recalled; 0 restores the stand-in of ABI <= 4. ---- */
+  int32_t ndt_newton_solver;            /* upstream evaluation orders (ndt_strict_order >= 1): 1 = Eigen::JacobiSVD's own two-sided Jacobi sequence
+                                           (what computeTransformation's `sv.solve(-score_gradient)` runs); 0 = one-sided Hestenes Jacobi.  The FAST
+                                           order keeps its Gauss-Jordan step either way. */
+  int32_t ndt_hessian_recompute_double; /* computeStepLengthMT ends with computeHessian when the line search took extra trials: 1 = PCL's double-precision
+                                           computeHessian / updateHessian, as ndt_omp kept it; 0 = the float computeDerivatives pass again.  Upstream
+                                           orders only (the FAST order re-runs its own float pass). */
+  int32_t ndt_guess_rotation_polar;     /* initial pose vector: Euler angles of Affine3f::rotation(), i.e. of the polar factor of the guess's 3x3
+                                           (a float JacobiSVD) = 1, of the raw 3x3 = 0.  All orders. */
+  int32_t reserved0;
 } dgs_params;
 
 /* What the callers read back after align(): hasConverged(), getFinalTransformation(), and the
@@ -298,6 +309,9 @@ int dgs_get_counts(dgs_handle* h, int64_t out[8]);
 /* Test hooks: single evaluations on the device, so tests can compare kernels with the oracle directly. */
 /* NDT computeDerivatives at pose p (6 doubles).  T16 NULL = build the float transform from p. */
 int dgs_ndt_derivatives(dgs_handle* h, const double* p6, const float* T16, double* score, double* grad6, double* hess36);
+/* NDT computeHessian in PCL's double-precision form at pose p (the pass computeStepLengthMT ends with when a line search took extra
+ * trials; dgs_params.ndt_hessian_recompute_double).  Upstream evaluation orders only (DGS_ERR_UNSUPPORTED otherwise). */
+int dgs_ndt_hessian_double(dgs_handle* h, const double* p6, double* hess36);
 /* NDT pose (x, y, z, rx, ry, rz) after every outer iteration of pair `pair` of the last align / align_batch;
  * poses6 holds up to 72 x 6 doubles, *len receives the number written (entry 0 is the initial guess). */
 int dgs_ndt_get_trajectory(dgs_handle* h, int32_t pair, double* poses6, int32_t* len);

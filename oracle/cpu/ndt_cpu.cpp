@@ -176,9 +176,9 @@ void NdtCpu::compute_angle_derivatives(const double p[6]) {
       {(-cx * sz - sx * sy * cz), (-cx * cz + sx * sy * sz), 0},           // f2
       {(-sx * sz + cx * sy * cz), (-cx * sy * sz - sx * cz), 0}};          // f3
   for (int i = 0; i < 8; i++)
-    for (int k = 0; k < 3; k++) j_ang[i][k] = static_cast<float>(J[i][k]);
+    for (int k = 0; k < 3; k++) { j_ang[i][k] = static_cast<float>(J[i][k]); j_ang_d[i][k] = J[i][k]; }
   for (int i = 0; i < 15; i++)
-    for (int k = 0; k < 3; k++) h_ang[i][k] = static_cast<float>(Hh[i][k]);
+    for (int k = 0; k < 3; k++) { h_ang[i][k] = static_cast<float>(Hh[i][k]); h_ang_d[i][k] = Hh[i][k]; }
 }
 
 // getNeighborhoodAtPoint{1,7,26} / radiusSearch (KDTREE) restated on the voxel map
@@ -328,6 +328,102 @@ double NdtCpu::derivatives_with(const float* T, const double p[6], double g[6], 
   return score;
 }
 
+// ---- computeHessian / updateHessian in PCL's double form (NdtParams::hessian_recompute_double) -------------------------------------
+// ndt_omp moved computeDerivatives / updateDerivatives to float matrices but kept PCL's computeHessian / updateHessian: a single,
+// unthreaded pass over the points that adds every (point, voxel) term straight into the 6x6 Hessian, in double -- x from the float
+// point, x' - mean from the float transformed point, the voxel's double inverse covariance, point gradient / Hessian from the double
+// angle vectors.  std::exp(double) is libm-dependent in its last bit; the restatement uses det_exp (linalg.hpp).  Dot products and the
+// 3x3 * 3 products are written left to right (Eigen's reduction order inside them cannot be known offline).
+// The (point, voxel) terms are formed in parallel and then added one by one in upstream's order, so the sums are upstream's sums.
+void NdtCpu::hessian_double(const double p[6], double H[36]) {
+  float T[16];
+  pose_to_matrix_f32(p, T);
+  compute_angle_derivatives(p);
+  hessian_double_with(T, H);
+}
+
+void NdtCpu::hessian_double_with(const float* T, double H[36]) {
+  evaluations++;
+  for (int k = 0; k < 36; k++) H[k] = 0.0;
+  int nthreads = prm.num_threads;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+  nthreads = 1;
+#endif
+  constexpr int64_t kChunk = 4096;
+  std::vector<double> terms(static_cast<size_t>(kChunk) * 27 * 36);
+  std::vector<int> counts(kChunk);
+  for (int64_t base = 0; base < ns; base += kChunk) {
+    const int64_t m = std::min<int64_t>(kChunk, ns - base);
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int64_t li = 0; li < m; li++) {
+      const int64_t idx = base + li;
+      const float* xp = source.data() + idx * 4;
+      float xt[3];
+      for (int r = 0; r < 3; r++) xt[r] = T[0 * 4 + r] * xp[0] + T[1 * 4 + r] * xp[1] + T[2 * 4 + r] * xp[2] + T[3 * 4 + r];
+      const Leaf* nb[27];
+      const int nn = neighbours(xt, nb);
+      int cnt = 0;
+      if (nn > 0) {
+        const double x[3] = {xp[0], xp[1], xp[2]};
+        auto dot3 = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+        // computePointDerivatives(x, point_gradient_, point_hessian_) -- the double overload
+        double pg[3][6] = {{1, 0, 0, 0, 0, 0}, {0, 1, 0, 0, 0, 0}, {0, 0, 1, 0, 0, 0}};
+        pg[1][3] = dot3(x, j_ang_d[0]); pg[2][3] = dot3(x, j_ang_d[1]);
+        pg[0][4] = dot3(x, j_ang_d[2]); pg[1][4] = dot3(x, j_ang_d[3]); pg[2][4] = dot3(x, j_ang_d[4]);
+        pg[0][5] = dot3(x, j_ang_d[5]); pg[1][5] = dot3(x, j_ang_d[6]); pg[2][5] = dot3(x, j_ang_d[7]);
+        double ph[6][6][3];
+        std::memset(ph, 0, sizeof(ph));
+        {
+          double xh[15];
+          for (int i = 0; i < 15; i++) xh[i] = dot3(x, h_ang_d[i]);
+          const double a[3] = {0, xh[0], xh[1]}, b[3] = {0, xh[2], xh[3]}, c[3] = {0, xh[4], xh[5]};
+          const double d[3] = {xh[6], xh[7], xh[8]}, e[3] = {xh[9], xh[10], xh[11]}, f[3] = {xh[12], xh[13], xh[14]};
+          for (int r = 0; r < 3; r++) {
+            ph[3][3][r] = a[r]; ph[3][4][r] = b[r]; ph[3][5][r] = c[r];
+            ph[4][3][r] = b[r]; ph[4][4][r] = d[r]; ph[4][5][r] = e[r];
+            ph[5][3][r] = c[r]; ph[5][4][r] = e[r]; ph[5][5][r] = f[r];
+          }
+        }
+        for (int v = 0; v < nn; v++) {
+          const Leaf* cell = nb[v];
+          const double* C = cell->icov;
+          const double q[3] = {static_cast<double>(xt[0]) - cell->mean[0], static_cast<double>(xt[1]) - cell->mean[1], static_cast<double>(xt[2]) - cell->mean[2]};
+          auto Cmul = [&](const double* w, double* out) {   // c_inv * w
+            for (int r = 0; r < 3; r++) out[r] = C[r * 3 + 0] * w[0] + C[r * 3 + 1] * w[1] + C[r * 3 + 2] * w[2];
+          };
+          double Cq[3];
+          Cmul(q, Cq);
+          double e_x_cov_x = gauss_d2 * det_exp(-gauss_d2 * dot3(q, Cq) / 2);
+          if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
+          e_x_cov_x *= gauss_d1;
+          double* out = terms.data() + (static_cast<size_t>(li) * 27 + cnt) * 36;
+          cnt++;
+          for (int i = 0; i < 6; i++) {
+            const double pgi[3] = {pg[0][i], pg[1][i], pg[2][i]};
+            double cov_dxd_pi[3];
+            Cmul(pgi, cov_dxd_pi);
+            for (int j = 0; j < 6; j++) {
+              const double pgj[3] = {pg[0][j], pg[1][j], pg[2][j]};
+              double Cpgj[3], Cph[3];
+              Cmul(pgj, Cpgj);
+              Cmul(ph[i][j], Cph);
+              out[i * 6 + j] = e_x_cov_x * (-gauss_d2 * dot3(q, cov_dxd_pi) * dot3(q, Cpgj) + dot3(q, Cph) + dot3(pgj, cov_dxd_pi));
+            }
+          }
+        }
+      }
+      counts[li] = cnt;
+    }
+    for (int64_t li = 0; li < m; li++)
+      for (int v = 0; v < counts[li]; v++) {
+        const double* t = terms.data() + (static_cast<size_t>(li) * 27 + v) * 36;
+        for (int k = 0; k < 36; k++) H[k] += t[k];
+      }
+  }
+}
+
 // ---- More-Thuente helpers (PCL ndt.hpp restated; More & Thuente 1994, Sun & Yuan 2006) ------------
 static inline double psi_mt(double a, double f_a, double f_0, double g_0, double mu) { return f_a - f_0 - mu * g_0 * a; }
 static inline double dpsi_mt(double g_a, double g_0, double mu) { return g_a - mu * g_0; }
@@ -396,7 +492,16 @@ NdtResult NdtCpu::align(const float* guess, double* trajectory, int* traj_len) {
   float final_T[16];
   std::memcpy(final_T, guess, sizeof(final_T));
   float eul[3];
-  euler_angles_012(guess, eul);
+  if (prm.guess_rotation_polar) {   // eig_transformation.rotation().eulerAngles(0, 1, 2): Affine3f::rotation() is the polar factor
+    float R[9], G[16];
+    affine_rotation_f32(guess, R);
+    std::memcpy(G, guess, sizeof(G));
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) G[c * 4 + r] = R[r * 3 + c];
+    euler_angles_012(G, eul);
+  } else {
+    euler_angles_012(guess, eul);
+  }
   double p[6] = {guess[12], guess[13], guess[14], eul[0], eul[1], eul[2]};
   double g[6], H[36], delta[6];
   int tl = 0;
@@ -411,7 +516,7 @@ NdtResult NdtCpu::align(const float* guess, double* trajectory, int* traj_len) {
   while (!converged) {
     double neg_g[6];
     for (int k = 0; k < 6; k++) neg_g[k] = -g[k];
-    svd_solve6(H, neg_g, delta);
+    if (prm.newton_solver) jsvd_solve6(H, neg_g, delta); else svd_solve6(H, neg_g, delta);
     double norm = 0;
     for (int k = 0; k < 6; k++) norm += delta[k] * delta[k];
     norm = std::sqrt(norm);
@@ -489,9 +594,14 @@ NdtResult NdtCpu::align(const float* guess, double* trajectory, int* traj_len) {
             interval_converged = update_interval_mt(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
           step_iterations++;
         }
-        if (step_iterations) {  // computeHessian at the accepted point (score/gradient are re-derived identically)
-          double g2[6];
-          derivatives_with(final_T, x_t, g2, H, true);
+        if (step_iterations) {  // computeHessian(hessian, trans_cloud, x_t) at the accepted point
+          res.hessian_recomputes++;
+          if (prm.hessian_recompute_double) {
+            hessian_double_with(final_T, H);   // angle tables: those of the last trial's computeDerivatives, i.e. of x_t
+          } else {   // rounds 1-3: the float pass again (score / gradient are re-derived identically)
+            double g2[6];
+            derivatives_with(final_T, x_t, g2, H, true);
+          }
         }
       }
     }

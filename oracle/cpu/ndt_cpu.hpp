@@ -34,6 +34,13 @@ struct NdtParams {
   int fix_hessian_d1 = 0;                // 0 = upstream table (h_ang_d1 z-term +sy), 1 = exact second derivative (-sy)
   int num_threads = 0;                   // registrations.cpp:102,106-108 (0 = all cores)
   int exp_libm = 0;                      // 0 = det_expf (linalg.hpp: platform-independent value of std::exp(float)), 1 = the host libm's expf
+  // ---- round 4: three upstream details that rounds 1-3 replaced by stand-ins (all [UPSTREAM-RECALL]) ----
+  int newton_solver = 1;                 // 1 = Eigen::JacobiSVD's own two-sided Jacobi sequence (linalg.hpp jsvd_solve6); 0 = one-sided Hestenes Jacobi (rounds 1-3)
+  int hessian_recompute_double = 1;      // computeStepLengthMT's closing computeHessian: 1 = PCL's double-precision computeHessian / updateHessian
+                                         // (double x, x' - mean, inverse covariance, double angle tables, ONE pass accumulating straight into the
+                                         // Hessian in index order), as ndt_omp kept it; 0 = the float computeDerivatives pass run again (rounds 1-3)
+  int guess_rotation_polar = 1;          // initial p: Euler angles of Affine3f::rotation() = the polar factor of the guess's 3x3 (a float JacobiSVD);
+                                         // 0 = Euler angles of the raw 3x3 (rounds 1-3)
 };
 
 struct Leaf {
@@ -53,6 +60,7 @@ struct NdtResult {
   int converged;
   int iterations;   // nr_iterations_
   int evaluations;  // computeDerivatives calls (+ hessian recomputations)
+  int hessian_recomputes;  // of which: computeHessian passes at the end of a line search that took extra trials
   double score;     // final score (trans_probability * Ns)
 };
 
@@ -66,6 +74,11 @@ class NdtCpu {
   double derivatives(const double p[6], double g[6], double H[36], bool compute_hessian = true);
   // same, but the cloud is transformed by an explicit float 4x4 (the first evaluation of align uses the guess)
   double derivatives_with(const float* T_colmajor16, const double p[6], double g[6], double H[36], bool compute_hessian);
+  // computeHessian(hessian, trans_cloud, p) in PCL's double form (hessian_recompute_double); uses the angle tables of the LAST
+  // compute_angle_derivatives call, as upstream does ("unnecessary because only used after regular derivative calculation")
+  void hessian_double_with(const float* T_colmajor16, double H[36]);
+  // test hook: angle tables at p, then hessian_double_with
+  void hessian_double(const double p[6], double H[36]);
 
   NdtParams prm;
   std::vector<float> target, source;  // xyz16
@@ -83,6 +96,8 @@ class NdtCpu {
   int neighbours(const float xt[3], const Leaf** out) const;
   float j_ang[8][3];
   float h_ang[15][3];
+  double j_ang_d[8][3];   // the double vectors j_ang_a_ .. h_ang_f3_ upstream keeps beside the float matrices
+  double h_ang_d[15][3];
 };
 
 // Eigen::Matrix3f::eulerAngles(0,1,2) (Eigen 3.3 algorithm) on the rotation block of a col-major float 4x4.

@@ -28,6 +28,9 @@ void orc_ndt_default_params(orc_ndt_params* p) {
   p->num_threads = d.num_threads;
   p->fix_hessian_d1 = d.fix_hessian_d1;
   p->exp_libm = d.exp_libm;
+  p->newton_solver = d.newton_solver;
+  p->hessian_recompute_double = d.hessian_recompute_double;
+  p->guess_rotation_polar = d.guess_rotation_polar;
 }
 
 void* orc_ndt_create(const orc_ndt_params* p) {
@@ -45,6 +48,9 @@ void* orc_ndt_create(const orc_ndt_params* p) {
   d.num_threads = p->num_threads;
   d.fix_hessian_d1 = p->fix_hessian_d1;
   d.exp_libm = p->exp_libm;
+  d.newton_solver = p->newton_solver;
+  d.hessian_recompute_double = p->hessian_recompute_double;
+  d.guess_rotation_polar = p->guess_rotation_polar;
   return new NdtCpu(d);
 }
 void orc_ndt_destroy(void* h) { delete static_cast<NdtCpu*>(h); }
@@ -58,7 +64,7 @@ void orc_ndt_align(void* h, const float* guess16, orc_result* out, double* traje
   out->converged = r.converged;
   out->iterations = r.iterations;
   out->evaluations = r.evaluations;
-  out->pad = 0;
+  out->pad = r.hessian_recomputes;   // diagnostics: computeHessian passes among the evaluations
   out->score = r.score;
   if (traj_len) *traj_len = tl;
 }
@@ -108,6 +114,14 @@ void orc_ndt_grid(void* h, int32_t* min_b3, int32_t* max_b3, int32_t* div_b3) {
 void orc_euler_angles_012(const float* T16, float* out3) { euler_angles_012(T16, out3); }
 void orc_pose_to_matrix_f32(const double* p6, float* T16) { pose_to_matrix_f32(p6, T16); }
 void orc_svd_solve6(const double* A, const double* b, double* x) { svd_solve6(A, b, x); }
+void orc_jsvd_solve6(const double* A, const double* b, double* x, int32_t* sr) {
+  JsvdStats st{0, 0};
+  jsvd_solve6(A, b, x, &st);
+  if (sr) { sr[0] = st.sweeps; sr[1] = st.rotations; }
+}
+void orc_affine_rotation_f32(const float* T16, float* R9) { affine_rotation_f32(T16, R9); }
+void orc_ndt_hessian_double(void* h, const double* p6, double* H36) { static_cast<NdtCpu*>(h)->hessian_double(p6, H36); }
+double orc_det_exp(double x) { return det_exp(x); }
 void orc_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); }
 void orc_sym_eig3(const double* A, double* ev, double* V) { sym_eig3(A, ev, V); }
 int32_t orc_max_threads(void) {

@@ -11,6 +11,7 @@ extern "C" {
 typedef struct orc_ndt_params {
   double resolution, step_size, outlier_ratio, transformation_epsilon, min_covar_eigvalue_mult;
   int32_t max_iterations, search_method, min_points_per_voxel, line_search, mt_max_step_iterations, num_threads, fix_hessian_d1, exp_libm;
+  int32_t newton_solver, hessian_recompute_double, guess_rotation_polar;   /* round 4: NdtParams in ndt_cpu.hpp */
 } orc_ndt_params;
 
 typedef struct orc_result {
@@ -32,6 +33,10 @@ void orc_ndt_grid(void* h, int32_t* min_b3, int32_t* max_b3, int32_t* div_b3);
 void orc_euler_angles_012(const float* T16, float* out3);
 void orc_pose_to_matrix_f32(const double* p6, float* T16);
 void orc_svd_solve6(const double* A36, const double* b6, double* x6);
+void orc_jsvd_solve6(const double* A36, const double* b6, double* x6, int32_t* sweeps_rotations2);
+void orc_affine_rotation_f32(const float* T16, float* R9_rowmajor);
+void orc_ndt_hessian_double(void* h, const double* p6, double* H36);
+double orc_det_exp(double x);
 void orc_ldlt_solve6(const double* A36, const double* b6, double* x6);
 void orc_sym_eig3(const double* A9, double* evals3, double* V9);
 int32_t orc_max_threads(void);

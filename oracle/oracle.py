@@ -38,7 +38,8 @@ class NdtParams(C.Structure):
                 ("transformation_epsilon", C.c_double), ("min_covar_eigvalue_mult", C.c_double),
                 ("max_iterations", C.c_int32), ("search_method", C.c_int32), ("min_points_per_voxel", C.c_int32),
                 ("line_search", C.c_int32), ("mt_max_step_iterations", C.c_int32), ("num_threads", C.c_int32),
-                ("fix_hessian_d1", C.c_int32), ("exp_libm", C.c_int32)]
+                ("fix_hessian_d1", C.c_int32), ("exp_libm", C.c_int32),
+                ("newton_solver", C.c_int32), ("hessian_recompute_double", C.c_int32), ("guess_rotation_polar", C.c_int32)]
 
 
 class GicpParams(C.Structure):
@@ -103,7 +104,8 @@ class NdtOracle:
 
     def __init__(self, resolution=1.0, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
                  step_size=0.1, outlier_ratio=0.55, line_search=1, num_threads=0, min_points_per_voxel=6,
-                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False, exp_libm=0):
+                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False, exp_libm=0,
+                 newton_solver=1, hessian_recompute_double=1, guess_rotation_polar=1):
         L = lib(perturbed)
         self._L = L
         p = NdtParams()
@@ -121,6 +123,10 @@ class NdtOracle:
         p.mt_max_step_iterations = mt_max_step_iterations
         p.fix_hessian_d1 = fix_hessian_d1
         p.exp_libm = exp_libm   # 1: the host libm's expf instead of the platform-independent det_expf (a <= 1 ulp perturbation)
+        # round 4 (ndt_cpu.hpp): Eigen's two-sided JacobiSVD sequence / PCL's double computeHessian / Affine3f::rotation() -- 0 = rounds 1-3
+        p.newton_solver = newton_solver
+        p.hessian_recompute_double = hessian_recompute_double
+        p.guess_rotation_polar = guess_rotation_polar
         self.params = p
         self.max_iterations = max_iterations
         self._h = C.c_void_p(L.orc_ndt_create(C.byref(p)))
@@ -149,7 +155,8 @@ class NdtOracle:
         self._L.orc_ndt_align(self._h, g.ctypes.data_as(C.POINTER(C.c_float)), C.byref(res),
                             traj.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tl))
         return dict(T=_from_colmajor16(res.T), converged=bool(res.converged), iterations=res.iterations,
-                    evaluations=res.evaluations, score=res.score, trajectory=traj[:tl.value].copy())
+                    evaluations=res.evaluations, score=res.score, trajectory=traj[:tl.value].copy(),
+                    hessian_recomputes=res.pad)
 
     def derivatives(self, p, T=None, compute_hessian=True):
         p, pp = _f64c(p)
@@ -162,6 +169,13 @@ class NdtOracle:
         s = self._L.orc_ndt_derivatives(self._h, pp, Tp, g.ctypes.data_as(C.POINTER(C.c_double)),
                                       H.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(1 if compute_hessian else 0))
         return s, g, H
+
+    def hessian_double(self, p):
+        """computeHessian in PCL's double form at pose p (ndt_cpu.cpp hessian_double_with)."""
+        p, pp = _f64c(p)
+        H = np.zeros((6, 6))
+        self._L.orc_ndt_hessian_double(self._h, pp, H.ctypes.data_as(C.POINTER(C.c_double)))
+        return H
 
     def voxels(self):
         L = self._L
@@ -206,6 +220,31 @@ def svd_solve6(A, b):
     x = np.zeros(6)
     lib().orc_svd_solve6(pa, pb, x.ctypes.data_as(C.POINTER(C.c_double)))
     return x
+
+
+def jsvd_solve6(A, b, stats=False):
+    """Eigen::JacobiSVD<Matrix6d>(A, FullU | FullV).solve(b) restated (linalg.hpp jsvd_solve6); stats -> (x, sweeps, rotations)."""
+    a, pa = _f64c(np.asarray(A, np.float64).reshape(36))
+    bb, pb = _f64c(b)
+    x = np.zeros(6)
+    sr = (C.c_int32 * 2)()
+    lib().orc_jsvd_solve6(pa, pb, x.ctypes.data_as(C.POINTER(C.c_double)), sr)
+    return (x, int(sr[0]), int(sr[1])) if stats else x
+
+
+def affine_rotation_f32(T) -> np.ndarray:
+    """Eigen::Affine3f::rotation() of a 4x4 (polar factor through a float JacobiSVD), 3x3 float32."""
+    t = _colmajor16(T)
+    R = np.zeros(9, np.float32)
+    lib().orc_affine_rotation_f32(t.ctypes.data_as(C.POINTER(C.c_float)), R.ctypes.data_as(C.POINTER(C.c_float)))
+    return R.reshape(3, 3)
+
+
+def det_exp(x: float) -> float:
+    L = lib()
+    L.orc_det_exp.restype = C.c_double
+    L.orc_det_exp.argtypes = [C.c_double]
+    return float(L.orc_det_exp(float(x)))
 
 
 def ldlt_solve6(A, b):

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in dgs_reg.h but not exported"
     assert sorted(L.SYMBOLS) == declared
-    assert lib.dgs_abi_version() == 4
+    assert lib.dgs_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header():
