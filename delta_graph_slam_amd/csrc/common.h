@@ -58,7 +58,8 @@ enum NdtPhase : int {
   PH_MT_TRIAL = 2,    // waiting for score + gradient at a More-Thuente trial step
   PH_MT_HESSIAN = 3,  // waiting for the Hessian at the accepted step
   PH_PROBE = 4,       // test hook: reduce only
-  PH_DONE = 5
+  PH_DONE = 5,
+  PH_SOLVE_PENDING = 6   // upstream order: the iteration has been closed, its Newton step is left to ndt_strict_solve_kernel (ndt_strict.h)
 };
 
 // Optimiser state proper: the solve kernel copies it into registers, advances it with every lane of one wave computing
@@ -100,12 +101,16 @@ struct NdtPair {
   // j_ang_a_ .. h_ang_f3_ of the evaluation's pose, which upstream keeps beside the float matrices
   double jang_d[8][3];
   double hang_d[15][3];
-  // fused launches of the upstream order (ndt_strict.h): two kernels per round -- [0] evaluation kinds 0 / 1, [1] kind 2 -- and the pair
-  // takes part in the kernel of type t of round r while r <= serve[t].  Its closing workgroup raises the word of the kernel that serves
-  // the evaluation it has just queued; a word only ever grows, and never past the round that reads it plus one, so every workgroup of a
-  // running launch sees the same set of pairs whatever the moment it looks (the default order's last_launch plays this part there).
-  int serve[2];
-  int pad_serve[2];
+  // fused launches of the upstream order (ndt_strict.h), two kernels per round.  The first kernel (evaluation kinds 0 / 1) of round r
+  // takes a pair when r <= serve[0] or r == serve[2]; the second (kind 2, the double computeHessian pass) when r == serve[1].
+  //   serve[0]: raised to r + 1 by the pair's closing in the first kernel of round r when the evaluation it queues is of kind 0 / 1.  The
+  //             word only grows, and never past the reading round plus one: every workgroup of the running launch keeps seeing the pair.
+  //   serve[1]: set to r by that closing when it queues kind 2: the second kernel of the SAME round serves it.
+  //   serve[2]: set to r + lag by the pair's closing in the second kernel of round r.  With lag = 2 the second kernel of round r may run
+  //             BESIDE the first kernel of round r + 1 (its own stream): an exact match, so a value written while that launch runs
+  //             (r + 2) is read as "not this round" before and after the store alike.
+  // The item-compacted kernel (one launch per round) uses serve[0] alone.
+  int serve[4];
 };
 
 // ---- per-pair GICP optimiser state (fast_gicp::LsqRegistration) -------------------------------
@@ -184,7 +189,7 @@ struct NdtInit {  // host -> device per pair, per align
 // Returns false when this workgroup has nothing to do.  gridDim.x must be >= the number of pairs.
 #ifdef __HIPCC__
 template <class Pred>
-__device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, Pred pred, int& pair, int& slice, int& blocks_per_pair) {
+__device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, Pred pred, int& pair, int& slice, int& blocks_per_pair, int* n_active_out = nullptr) {
   const int lane_id = threadIdx.x & 63;
   int n_active = 0;
   for (int c0 = 0; c0 < n_pairs; c0 += 64) {
@@ -192,6 +197,7 @@ __device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, P
     const bool a = (pi < n_pairs) && pred(pi);
     n_active += __popcll(__ballot(a));
   }
+  if (n_active_out) *n_active_out = n_active;
   if (n_active == 0) return false;
   blocks_per_pair = max(1, min((int)gridDim.x / n_active, cap_blocks));
   const int rank = blockIdx.x / blocks_per_pair;

@@ -48,6 +48,14 @@ static int side_create(dgs_handle* h) {
   DGS_HIP_TRY(h, hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_low));
   DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  // the computeHessian stream of the upstream NDT order: same priority as the main stream, its own hardware queue (created third)
+  if (h->prm.method == DGS_METHOD_NDT) {
+    DGS_HIP_TRY(h, hipStreamCreateWithFlags(&h->hd_stream, hipStreamNonBlocking));
+    for (int k = 0; k < dgs_handle::kHdEvents; k++) {
+      DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_hd_a[k], hipEventDisableTiming));
+      DGS_HIP_TRY(h, hipEventCreateWithFlags(&h->ev_hd_b[k], hipEventDisableTiming));
+    }
+  }
   return DGS_OK;
 }
 
@@ -76,7 +84,7 @@ int side_join(dgs_handle* h) {
   return DGS_OK;
 }
 
-int prof_begin(dgs_handle* h, int kernel_id) {
+int prof_begin(dgs_handle* h, int kernel_id, hipStream_t st) {
   Profiler& p = h->prof;
   if (!p.enabled) return -1;
   if (p.next_free == p.pool.size()) {
@@ -85,21 +93,22 @@ int prof_begin(dgs_handle* h, int kernel_id) {
     p.pool.push_back(ep);
   }
   const int slot = (int)p.next_free++;
-  (void)hipEventRecord(p.pool[slot].start, h->stream);
+  (void)hipEventRecord(p.pool[slot].start, st ? st : h->stream);
   (void)kernel_id;
   return slot;
 }
 
-void prof_end(dgs_handle* h, int kernel_id, int slot) {
+void prof_end(dgs_handle* h, int kernel_id, int slot, hipStream_t st) {
   if (slot < 0) return;
   Profiler& p = h->prof;
-  (void)hipEventRecord(p.pool[slot].stop, h->stream);
+  (void)hipEventRecord(p.pool[slot].stop, st ? st : h->stream);
   p.pending[kernel_id].push_back(slot);
 }
 
 static void prof_collect(dgs_handle* h) {
   Profiler& p = h->prof;
   (void)hipStreamSynchronize(h->stream);
+  if (h->hd_stream) (void)hipStreamSynchronize(h->hd_stream);
   for (int k = 0; k < DGS_K_COUNT; k++) {
     for (int slot : p.pending[k]) {
       float ms = 0.f;
@@ -301,6 +310,8 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (kExperiments)   // the product library carries neither the grid index nor the packed-FP32 kernel (measured losers: `make experiments`)
     if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NDT_HD_OVERLAP")) h->hd_overlap = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NDT_SOLVE_MIN_ACTIVE")) h->solve_min_active = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("DGS_NDT_QUEUE")) h->ndt_queue_mode = std::atoi(e);
   if (const char* e = std::getenv("DGS_NDT_SCHEDULE")) h->ndt_schedule = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NDT_QUEUE_MIN_PAIRS")) h->ndt_queue_min_pairs = std::max(1, std::atoi(e));
@@ -334,6 +345,14 @@ void dgs_destroy(dgs_handle* h) {
   h->own_target.release(); h->own_source.release();
   for (int k = 0; k < 2; k++)
     if (h->ev_poll[k]) (void)hipEventDestroy(h->ev_poll[k]);
+  if (h->hd_stream) {
+    (void)hipStreamSynchronize(h->hd_stream);
+    (void)hipStreamDestroy(h->hd_stream);
+    for (int k = 0; k < dgs_handle::kHdEvents; k++) {
+      if (h->ev_hd_a[k]) (void)hipEventDestroy(h->ev_hd_a[k]);
+      if (h->ev_hd_b[k]) (void)hipEventDestroy(h->ev_hd_b[k]);
+    }
+  }
   if (h->side_stream) {
     (void)hipStreamSynchronize(h->side_stream);
     (void)hipStreamDestroy(h->side_stream);

@@ -110,6 +110,15 @@ struct dgs_handle {
   // side stream: small builds that the main stream does not need yet (the target's NN index while the batch iterates)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // third stream: the double-precision computeHessian launches of the upstream order run beside the main stream's launches (ndt_strict.h)
+  hipStream_t hd_stream = nullptr;
+  static constexpr int kHdEvents = 32;
+  hipEvent_t ev_hd_a[kHdEvents] = {}, ev_hd_b[kHdEvents] = {};
+  bool hd_overlap = true;             // DGS_NDT_HD_OVERLAP=0: the computeHessian launch of a round in line with the round's first launch
+  int solve_min_active = 0;           // DGS_NDT_SOLVE_MIN_ACTIVE (default 0 = the Newton step stays in the closing workgroup): item-compacted upstream-order kernel:
+                                      // with at least this many pairs in a launch the Newton steps go to ndt_strict_solve_kernel on the third stream.  Measured on the
+                                      // bench step: 6.58-6.65 ms with 2 / 4 / 8 / 16 against 6.24 ms in line -- a pair sits out a round per iteration, and the closings'
+                                      // ~45 us chains were already hidden behind the other pairs' derivative work
   bool side_pending = false;
   bool side_build_deferred = false;   // forked, launches still to be enqueued (side_build_now)
   std::string err;
@@ -244,8 +253,8 @@ struct dgs_handle {
 namespace dgs {
 
 // profiling wrappers (dgs_api.hip)
-int prof_begin(dgs_handle* h, int kernel_id);
-void prof_end(dgs_handle* h, int kernel_id, int slot);
+int prof_begin(dgs_handle* h, int kernel_id, hipStream_t st = nullptr);   // st: default the handle's stream
+void prof_end(dgs_handle* h, int kernel_id, int slot, hipStream_t st = nullptr);
 int ensure_pinned(dgs_handle* h, size_t bytes);
 int ensure_poll_events(dgs_handle* h);
 int side_fork(dgs_handle* h);   // side_stream continues from what the main stream has enqueued so far

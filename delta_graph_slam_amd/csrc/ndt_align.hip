@@ -930,11 +930,14 @@ __device__ __forceinline__ void queue_trial(NdtPair* st, NdtPair* hdr, NdtSolver
 // Consumes one evaluation result (already stored in s.score/grad/hess) and advances the state machine until
 // the next evaluation is queued or the registration is finished.  Executed by all lanes of one wave in lock step.
 // SVD_REGS: the stand-alone solve launch of the validation modes keeps the SVD workspace in registers (solve6.h)
+// defer_solve (upstream order, ndt_strict.h): stop in front of the next iteration's Newton step (phase PH_SOLVE_PENDING); a later call
+// with that phase -- from ndt_strict_solve_kernel -- continues there.
 template <bool SVD_REGS = false, bool COH = false, bool STRICT = false>
-__device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer) {
-  s.evaluations++;
+__device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer, bool defer_solve = false) {
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
-  switch (s.phase) {
+  const bool resume = STRICT && s.phase == PH_SOLVE_PENDING;
+  if (!resume) s.evaluations++;
+  switch (resume ? PH_INIT_EVAL : s.phase) {
     case PH_PROBE:
       s.phase = PH_DONE;
       return;
@@ -985,6 +988,10 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
   for (int guard = 0; guard < 4096; guard++) {
     if (iteration_open) {
       if (end_iteration(st, s, c, writer)) return;
+    }
+    if (STRICT && defer_solve) {   // the Newton step goes to the solve kernel
+      s.phase = PH_SOLVE_PENDING;
+      return;
     }
     if (begin_iteration<STRICT, SVD_REGS, COH>(st, hdr, s, c, writer)) return;  // evaluation queued
     if (s.phase == PH_DONE) return;
@@ -1526,6 +1533,8 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   st->ticket = 0;
   st->serve[0] = 0;    // upstream order, fused: the first evaluation (kind 1) is served by round 0's first kernel
   st->serve[1] = -1;
+  st->serve[2] = -1;
+  st->serve[3] = 0;
   if (queue) {   // queue kernel: the record slot of round 0
     const int* from = reinterpret_cast<const int*>(st);
     int* to = reinterpret_cast<int*>(queue_slot(ring, ring_rounds, i, 0));
@@ -1748,9 +1757,18 @@ static void launch_strict_rows(dgs_handle* h, const NdtLaunch& L, const dim3 gri
 // ndt_strict_order 1: ndt_strict_kernel (ndt_strict.h); launch >= 0: fused (derivatives + closing workgroups), < 0: derivatives only.
 // hd: the instantiation for the pairs waiting for the double-precision computeHessian pass (evaluation kind 2).
 // DGS_NDT_STRICT_KERNEL=2: the lane-per-point kernels (two launches per round); default 3: the item-compacted kernel (one launch per round)
+// (Measured and dropped: the item-compacted kernel for the float kinds alone -- 64-point tiles, a third of the LDS, meant for three waves
+// per SIMD -- with the lane-per-point computeHessian kernel as the round's second launch: the register allocator spilled the double
+// accumulators, 47 ms per step.)
 static int strict_kernel_version() {
   static const int v = std::getenv("DGS_NDT_STRICT_KERNEL") ? std::atoi(std::getenv("DGS_NDT_STRICT_KERNEL")) : 3;
   return v == 2 ? 2 : 3;
+}
+
+// item-compacted kernel, fused launches: the Newton steps of the closings go to ndt_strict_solve_kernel on the third stream
+static bool strict_solve_beside(const dgs_handle* h) {
+  return strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25) && h->ndt_fused && h->solve_min_active > 0 && h->hd_stream != nullptr &&
+         h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM;
 }
 
 template <int SEARCH>
@@ -1758,18 +1776,21 @@ static void launch_strict_sums(dgs_handle* h, const NdtLaunch& L, const dim3 gri
   if (strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25)) {
     if (hd && launch >= 0) return;   // one kernel serves every kind (launch < 0: the test hook asks for the kind it has set up)
     if (launch >= 0)
-      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
+      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
                          h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
-                         h->done_flags, launch);
+                         h->done_flags, launch, strict_solve_beside(h) ? h->solve_min_active : 0);
     else
-      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, false>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
+      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, false, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
                          h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
-                         h->done_counter.ptr, launch);
+                         h->done_counter.ptr, launch, 0);
     return;
   }
+  const bool beside = hd && launch >= 0 && h->hd_overlap && h->hd_stream;   // the computeHessian launch on its own stream, beside the next round's first launch
+  hipStream_t lst = beside ? h->hd_stream : h->stream;
+  const int hd_lag = (launch >= 0 && h->hd_overlap && h->hd_stream) ? 2 : 1;
 #define DGS_LAUNCH_SS(FUSED, HD, FLAGS)                                                                                                                          \
-  hipLaunchKernelGGL((ndt_strict_kernel<SEARCH, FUSED, HD>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr, \
-                     h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts, FLAGS, launch)
+  hipLaunchKernelGGL((ndt_strict_kernel<SEARCH, FUSED, HD>), grid, dim3(kBlock), 0, lst, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr, \
+                     h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts, FLAGS, launch, hd_lag)
   if (launch >= 0) {
     if (hd) DGS_LAUNCH_SS(true, true, h->done_flags); else DGS_LAUNCH_SS(true, false, h->done_flags);
   } else {
@@ -1785,7 +1806,8 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
   const float gd2 = (float)h->consts.gauss_d2;
   int fe = 0;
   const int leaf_pow2 = (std::frexp(h->grid.leaf, &fe) == 0.5f) ? 1 : 0;
-  int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES);
+  hipStream_t pst = (hd && launch >= 0 && h->hd_overlap && h->hd_stream && h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM) ? h->hd_stream : h->stream;   // launch_strict_sums
+  int slot = prof_begin(h, DGS_K_NDT_DERIVATIVES, pst);
   if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM_SEQUENTIAL) {
     switch (h->consts.search_method) {
       case DGS_NDT_DIRECT1: launch_strict_rows<DGS_NDT_DIRECT1>(h, L, grid, leaf_pow2); break;
@@ -1803,7 +1825,7 @@ static void launch_derivatives(dgs_handle* h, const NdtLaunch& L, int launch = -
       case DGS_NDT_KDTREE: launch_strict_sums<DGS_NDT_KDTREE>(h, L, grid, leaf_pow2, launch, hd); break;
       default: launch_strict_sums<DGS_NDT_DIRECT7>(h, L, grid, leaf_pow2, launch, hd); break;
     }
-    prof_end(h, DGS_K_NDT_DERIVATIVES, slot);
+    prof_end(h, DGS_K_NDT_DERIVATIVES, slot, pst);
     return;
   }
 #define DGS_LAUNCH_DERIV(SEARCH, FUSED, PACK)                                                                                                            \
@@ -2044,6 +2066,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   if (schedule) choose_queue(h, Lq);
   int round_no = 0;
   int launches_upto[2] = {0, 0};   // launches enqueued up to the end of the chunk of either slot
+  int hd_rounds = 0;               // rounds whose computeHessian launch went to its own stream
   auto enqueue_chunk = [&](int slot, int launches) -> int {
     for (int e = 0; e < launches; e++) {
       NdtLaunch Lr = L;
@@ -2054,8 +2077,32 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
       round_no++;
       const bool two_kinds = h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM && h->consts.hessian_double && !(strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25));   // ndt_strict.h, lane-per-point kernels: kinds 0 / 1, then kind 2
       if (fused) {
-        launch_derivatives(h, Lr, launch_no);
-        if (two_kinds) launch_derivatives(h, Lr, launch_no, true);   // same round number: NdtPair::serve
+        if (two_kinds && h->hd_overlap && h->hd_stream) {
+          // round r: [main] first kernel, [computeHessian stream] second kernel beside the first kernel of round r + 1; the first kernel of
+          // round r + 2 waits for it (NdtPair::serve, lag 2)
+          constexpr int R = dgs_handle::kHdEvents;
+          if (launch_no >= 2) DGS_HIP_TRY(h, hipStreamWaitEvent(st, h->ev_hd_b[(launch_no - 2) % R], 0));
+          launch_derivatives(h, Lr, launch_no);
+          DGS_HIP_TRY(h, hipEventRecord(h->ev_hd_a[launch_no % R], st));
+          DGS_HIP_TRY(h, hipStreamWaitEvent(h->hd_stream, h->ev_hd_a[launch_no % R], 0));
+          launch_derivatives(h, Lr, launch_no, true);
+          DGS_HIP_TRY(h, hipEventRecord(h->ev_hd_b[launch_no % R], h->hd_stream));
+          hd_rounds = launch_no + 1;
+        } else if (h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM && strict_solve_beside(h)) {
+          // round r: [main] the derivative launch; [third stream] the Newton steps its closings left behind, beside the launch of round r + 1;
+          // the launch of round r + 2 waits for them (NdtPair::serve, lag 2)
+          constexpr int R = dgs_handle::kHdEvents;
+          if (launch_no >= 2) DGS_HIP_TRY(h, hipStreamWaitEvent(st, h->ev_hd_b[(launch_no - 2) % R], 0));
+          launch_derivatives(h, Lr, launch_no);
+          DGS_HIP_TRY(h, hipEventRecord(h->ev_hd_a[launch_no % R], st));
+          DGS_HIP_TRY(h, hipStreamWaitEvent(h->hd_stream, h->ev_hd_a[launch_no % R], 0));
+          hipLaunchKernelGGL(ndt_strict_solve_kernel, dim3(n_pairs), dim3(kWave), 0, h->hd_stream, h->pairs.ptr, n_pairs, h->consts, h->done_flags, launch_no, 2);
+          DGS_HIP_TRY(h, hipEventRecord(h->ev_hd_b[launch_no % R], h->hd_stream));
+          hd_rounds = launch_no + 1;
+        } else {
+          launch_derivatives(h, Lr, launch_no);
+          if (two_kinds) launch_derivatives(h, Lr, launch_no, true);   // same round number: NdtPair::serve
+        }
         launch_no++;
       } else {
         launch_derivatives(h, Lr);
@@ -2126,6 +2173,10 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
     if (pairs_done(cur) >= n_pairs) { finished = true; break; }
     if (!more) break;
     cur ^= 1;
+  }
+  if (hd_rounds > 0) {   // the main stream takes the computeHessian stream's launches in (they are in order: the last one covers them all)
+    hipError_t e = hipStreamWaitEvent(st, h->ev_hd_b[(hd_rounds - 1) % dgs_handle::kHdEvents], 0);
+    if (e != hipSuccess && rc == DGS_OK) { h->err = std::string("hipStreamWaitEvent: ") + hipGetErrorString(e); rc = DGS_ERR_HIP; }
   }
   if (rc != DGS_OK) return rc;
   (void)finished;  // pairs that did not finish inside max_evals export converged = 0

@@ -318,8 +318,15 @@ __device__ __forceinline__ void strict_block_row(const double (&acc)[kStrictAccu
 // launch, rows read with the hand-off's coherent loads, the pair leaves through last_launch + its host flag).
 // HD / ONE_KERNEL: which kernel of the round runs this closing -- see NdtPair::serve.  ONE_KERNEL (ndt_strict3_kernel): every evaluation
 // kind is served by the round's only launch.
+#ifdef DGS_CLOSE_STAMPS   // diagnostic build (make dbg): 100 MHz wall-clock stamps of the closing phases while the pair is in its second iteration
+#define STRICT_STAMP(k) if (threadIdx.x == 0 && st->s.nr_iterations == 1) st->traj[kTrajCap - 1][k] = (double)wall_clock64();
+#else
+#define STRICT_STAMP(k)
+#endif
 template <bool HD, bool ONE_KERNEL = false>
-__device__ __forceinline__ void ndt_close_strict(NdtPair* st, const double* rows_of_pair, const int blocks_per_pair, const NdtConsts& c, int* done_flag, const int launch) {
+__device__ __forceinline__ void ndt_close_strict(NdtPair* st, const double* rows_of_pair, const int blocks_per_pair, const NdtConsts& c, int* done_flag, const int launch,
+                                                 const int hd_lag = 1, const bool defer_solve = false) {
+  STRICT_STAMP(0)
   __shared__ NdtSolver s_lds;
   NdtSolver& s = s_lds;
   static_assert(sizeof(NdtSolver) % 8 == 0 && sizeof(NdtSolver) / 8 <= kBlock, "state words");
@@ -355,6 +362,7 @@ __device__ __forceinline__ void ndt_close_strict(NdtPair* st, const double* rows
     tot[threadIdx.x] = t;
   }
   __syncthreads();
+  STRICT_STAMP(1)
   if (threadIdx.x >= kWave) return;
   const bool writer = threadIdx.x == 0;
   {
@@ -369,10 +377,13 @@ __device__ __forceinline__ void ndt_close_strict(NdtPair* st, const double* rows
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
   }
-  ndt_advance<false, false, true>(st, st, s, c, writer);
+  STRICT_STAMP(2)
+  ndt_advance<false, false, true>(st, st, s, c, writer, defer_solve);
+  STRICT_STAMP(3)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
   for (int w = threadIdx.x; w < kWords; w += kWave) reinterpret_cast<double*>(&st->s)[w] = reinterpret_cast<const double*>(&s_lds)[w];
+  STRICT_STAMP(4)
   if (writer) {
     if (s.phase == PH_DONE) {
       st->active = 0;
@@ -384,8 +395,10 @@ __device__ __forceinline__ void ndt_close_strict(NdtPair* st, const double* rows
       }
     } else if (launch >= 0) {
       // which kernel of which round serves the evaluation just queued (NdtPair::serve); `launch` is the round number
-      if (ONE_KERNEL) st->serve[0] = launch + 1;
-      else if (st->need_hessian == 2) st->serve[1] = HD ? launch + 1 : launch;   // the double computeHessian kernel of this round follows this launch
+      if (s.phase == PH_SOLVE_PENDING) st->serve[1] = launch;   // ndt_strict_solve_kernel of this round (its own stream) takes the Newton step
+      else if (ONE_KERNEL) st->serve[0] = launch + 1;
+      else if (st->need_hessian == 2) st->serve[1] = HD ? launch + hd_lag : launch;   // the double computeHessian kernel of this round follows this launch
+      else if (HD) st->serve[2] = launch + hd_lag;   // see NdtPair::serve
       else st->serve[0] = launch + 1;
     }
   }
@@ -403,10 +416,12 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
                                                               const VoxelGrid g, const VoxelStrictRec* __restrict__ vs, const double* __restrict__ vtab,
                                                               const double gauss_d1, const double gauss_d2, const int leaf_pow2, double* __restrict__ partials,
                                                               const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks, const NdtConsts consts,
-                                                              int* __restrict__ done_flags, const int launch) {
+                                                              int* __restrict__ done_flags, const int launch, const int hd_lag) {
   int pair, slice, blocks_per_pair;
-  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return FUSED ? (launch <= pairs[pi].serve[HD ? 1 : 0]) : (pairs[pi].active != 0 && (pairs[pi].need_hessian == 2) == HD); },
-                      pair, slice, blocks_per_pair)) return;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) {
+        if (!FUSED) return pairs[pi].active != 0 && (pairs[pi].need_hessian == 2) == HD;
+        return HD ? (launch == pairs[pi].serve[1]) : (launch <= pairs[pi].serve[0] || launch == pairs[pi].serve[2]);
+      }, pair, slice, blocks_per_pair)) return;
   if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
   const NdtPair& st = pairs[pair];
   const float4* __restrict__ src = src_ptrs[pair];
@@ -441,7 +456,10 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
   if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, blocks_per_pair) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
-  ndt_close_strict<HD>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch);
+#ifdef DGS_CLOSE_STAMPS
+  if (threadIdx.x == 0 && pairs[pair].s.nr_iterations == 1) pairs[pair].traj[kTrajCap - 1][5] = (double)wall_clock64();
+#endif
+  ndt_close_strict<HD>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch, hd_lag);
 }
 
 // ================================================================================================ item-compacted kernel (v3)
@@ -456,31 +474,36 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
 //     item's float increments to ITS double accumulators.  Every round but the last of a tile has all 64 lanes busy.
 // Which thread adds which item differs from the kernel above, i.e. the association of the double sums differs once more (~1e-14); every
 // float operation is the same (the same strict_item / strict_item_hd).  All three evaluation kinds run in ONE launch per round.
-template <int SEARCH>
+// WITH_HD = false: the kernel serves the float kinds only (64-point tiles, a third of the LDS, no double tables in registers: three waves
+// per SIMD instead of two); the pairs waiting for kind 2 are served by ndt_strict_kernel<SEARCH, FUSED, HD = true> as the round's second launch.
+template <int SEARCH, bool WITH_HD>
 struct StrictTile {
   static constexpr int NB = Offsets<SEARCH>::N;
-  static constexpr int PTS = (NB <= 7) ? 128 : 64;   // points per wave and tile (float kinds)
+  static constexpr int PTS = (NB <= 7 && WITH_HD) ? 128 : 64;   // points per wave and tile (float kinds)
   static constexpr int PTS_HD = 64;                  // double pass: 23 doubles + 3 floats per point
   static constexpr int kFields = 26;                 // xt[3], xj[8], xh[15]
-  static constexpr int kTableBytes = kFields * PTS * 4 > (23 * 8 + 3 * 4) * PTS_HD ? kFields * PTS * 4 : (23 * 8 + 3 * 4) * PTS_HD;
+  static constexpr int kTableBytes = (!WITH_HD || kFields * PTS * 4 > (23 * 8 + 3 * 4) * PTS_HD) ? kFields * PTS * 4 : (23 * 8 + 3 * 4) * PTS_HD;
   static constexpr int kQueue = PTS * NB;            // items of a tile at most
 };
 
-template <int SEARCH, bool FUSED>
+template <int SEARCH, bool FUSED, bool WITH_HD>
 __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes, NdtPair* __restrict__ pairs,
                                                                const VoxelGrid g, const VoxelStrictRec* __restrict__ vs, const double* __restrict__ vtab,
                                                                const double gauss_d1, const double gauss_d2, const int leaf_pow2, double* __restrict__ partials,
                                                                const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks, const NdtConsts consts,
-                                                               int* __restrict__ done_flags, const int launch) {
-  using TL = StrictTile<SEARCH>;
+                                                               int* __restrict__ done_flags, const int launch, const int solve_min_active) {
+  using TL = StrictTile<SEARCH, WITH_HD>;
   constexpr int NB = TL::NB;
   int pair, slice, blocks_per_pair;
-  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return FUSED ? (launch <= pairs[pi].serve[0]) : (pairs[pi].active != 0); }, pair, slice, blocks_per_pair)) return;
+  int n_active = 0;
+  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) {
+        return FUSED ? (launch <= pairs[pi].serve[0] || launch == pairs[pi].serve[2]) : (pairs[pi].active != 0 && (WITH_HD || pairs[pi].need_hessian != 2));
+      }, pair, slice, blocks_per_pair, &n_active)) return;
   if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
   const NdtPair& st = pairs[pair];
   const float4* __restrict__ src = src_ptrs[pair];
   const int n = src_sizes[pair];
-  const int kind = st.need_hessian;
+  const int kind = WITH_HD ? st.need_hessian : (st.need_hessian != 0 ? 1 : 0);
   const float gd2 = (float)gauss_d2;
   float T[12];
 #pragma unroll
@@ -496,12 +519,14 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
   double* td = reinterpret_cast<double*>(s_tab[wave]);          // double pass: [23][PTS_HD] doubles, then [3][PTS_HD] floats
   float* tdx = reinterpret_cast<float*>(s_tab[wave] + 23 * 8 * TL::PTS_HD);
   unsigned* queue = s_queue[wave];
-  const int pts = (kind == 2) ? TL::PTS_HD : TL::PTS;           // wave-uniform
+  const int pts = (WITH_HD && kind == 2) ? TL::PTS_HD : TL::PTS;           // wave-uniform
   const int subs = pts / 64;
   const int stride = blocks_per_pair * kBlock;
   // the wave's points: i = first + lane + sub * stride, tiles of `subs` strides
+#pragma unroll 1
   for (int first = slice * kBlock + wave * 64; first < n; first += subs * stride) {
     int qn = 0;
+#pragma unroll 1
     for (int sub = 0; sub < subs; sub++) {
       const int i = first + sub * stride + lane;
       const int slot = sub * 64 + lane;
@@ -515,7 +540,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
         xt[2] = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
         mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
         if (mask) {
-          if (kind == 2) {
+          if (WITH_HD && kind == 2) {
             double xj[8], xh[15];
             strict_point_tables_hd(x, st, xj, xh);
 #pragma unroll
@@ -551,12 +576,13 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     // ---- the items, 64 at a time
+#pragma unroll 1
     for (int h = 0; h < qn; h += 64) {
       const int idx = h + lane;
       if (idx < qn) {
         const unsigned entry = queue[idx];
         const int slot = (int)(entry >> 25), vid = (int)(entry & 0x1FFFFFFu);
-        if (kind == 2) {
+        if (WITH_HD && kind == 2) {
           double xj[8], xh[15];
           float xt[3];
 #pragma unroll
@@ -595,5 +621,41 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
   if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, blocks_per_pair) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
-  ndt_close_strict<false, true>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch);
+#ifdef DGS_CLOSE_STAMPS
+  if (threadIdx.x == 0 && pairs[pair].s.nr_iterations == 1) pairs[pair].traj[kTrajCap - 1][5] = (double)wall_clock64();
+#endif
+  // with enough other pairs to keep the chip busy the Newton step (a ~40 us dependent chain on one wave) leaves the launch: solve_min_active > 0
+  ndt_close_strict<false, WITH_HD>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch, 1,
+                                   solve_min_active > 0 && n_active >= solve_min_active);
+}
+
+// The Newton steps that the closings of round `launch` left behind (NdtPair::serve[1] == launch, phase PH_SOLVE_PENDING): one wave per pair,
+// on its own stream beside the next round's derivative launch.  The pair re-enters the derivative launches at round launch + lag.
+__global__ __launch_bounds__(kWave) void ndt_strict_solve_kernel(NdtPair* __restrict__ pairs, const int n_pairs, const NdtConsts c, int* __restrict__ done_flags, const int launch,
+                                                               const int lag) {
+  const int pair = blockIdx.x;
+  if (pair >= n_pairs) return;
+  NdtPair* st = pairs + pair;
+  if (st->serve[1] != launch || st->s.phase != PH_SOLVE_PENDING) return;
+  __shared__ NdtSolver s_lds;
+  NdtSolver& s = s_lds;
+  constexpr int kWords = (int)(sizeof(NdtSolver) / 8);
+  for (int w = threadIdx.x; w < kWords; w += kWave) reinterpret_cast<double*>(&s_lds)[w] = reinterpret_cast<const double*>(&st->s)[w];
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  const bool writer = threadIdx.x == 0;
+  ndt_advance<false, false, true>(st, st, s, c, writer, false);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  for (int w = threadIdx.x; w < kWords; w += kWave) reinterpret_cast<double*>(&st->s)[w] = reinterpret_cast<const double*>(&s_lds)[w];
+  if (writer) {
+    if (s.phase == PH_DONE) {
+      st->active = 0;
+      st->last_launch = launch;
+      __hip_atomic_store(done_flags + pair, launch + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      st->serve[2] = launch + lag;
+    }
+  }
 }
