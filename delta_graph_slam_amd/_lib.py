@@ -55,7 +55,7 @@ SYMBOLS = [
     "dgs_set_input_target_cloud", "dgs_set_input_source_cloud", "dgs_align_batch_clouds", "dgs_profile_enable",
     "dgs_profile_get", "dgs_profile_reset", "dgs_get_counts", "dgs_ndt_derivatives", "dgs_ndt_hessian_double", "dgs_ndt_get_voxels",
     "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize", "dgs_vgicp_get_voxels",
-    "dgs_group_create", "dgs_group_destroy", "dgs_group_last_error", "dgs_group_size", "dgs_group_uses_rccl", "dgs_group_last_gather_used_rccl",
+    "dgs_group_create", "dgs_group_destroy", "dgs_group_last_error", "dgs_group_size", "dgs_group_uses_rccl", "dgs_group_rccl_ranks", "dgs_group_last_gather_used_rccl",
     "dgs_group_member", "dgs_group_set_input_target", "dgs_group_align_batch",
     "dgs_group_cloud_create", "dgs_group_cloud_destroy", "dgs_group_cloud_size", "dgs_group_cloud_copies", "dgs_group_set_input_target_cloud",
     "dgs_group_align_batch_clouds",
@@ -125,6 +125,7 @@ def load(path=None):
     lib.dgs_group_last_error.restype = C.c_char_p
     lib.dgs_group_size.argtypes = [C.c_void_p]
     lib.dgs_group_uses_rccl.argtypes = [C.c_void_p]
+    lib.dgs_group_rccl_ranks.argtypes = [C.c_void_p]
     lib.dgs_group_last_gather_used_rccl.argtypes = [C.c_void_p]
     lib.dgs_group_member.argtypes = [C.c_void_p, C.c_int32]
     lib.dgs_group_member.restype = C.c_void_p

@@ -35,6 +35,7 @@ struct Rccl {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;   // optional: dgs_group_rccl_ranks
   bool ok() const { return lib != nullptr; }
 };
 constexpr int kNcclUint8 = 1;   // ncclDataType_t::ncclUint8 (rccl.h)
@@ -53,6 +54,7 @@ Rccl load_rccl() {
   r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
   r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
   if (!r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) {
     dlclose(r.lib);
     r.lib = nullptr;
@@ -436,6 +438,13 @@ void dgs_group_destroy(dgs_group* g) {
 const char* dgs_group_last_error(const dgs_group* g) { return g ? g->err.c_str() : ""; }
 int32_t dgs_group_size(const dgs_group* g) { return g ? (int32_t)g->members.size() : 0; }
 int32_t dgs_group_uses_rccl(const dgs_group* g) { return (g && !g->comms.empty()) ? 1 : 0; }
+// ranks of the group's RCCL communicator as RCCL itself reports them (ncclCommCount on member 0's communicator); 0 without RCCL
+int32_t dgs_group_rccl_ranks(const dgs_group* g) {
+  if (!g || g->comms.empty() || !g->rccl.CommCount) return 0;
+  int n = 0;
+  if (g->rccl.CommCount(g->comms[0], &n) != 0) return 0;
+  return n;
+}
 dgs_handle* dgs_group_member(dgs_group* g, int32_t k) { return (g && k >= 0 && (size_t)k < g->members.size()) ? g->members[k] : nullptr; }
 
 // runs job(k) for every member on its worker thread and waits; returns the first failing member's status

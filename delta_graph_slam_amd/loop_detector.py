@@ -20,6 +20,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Any, List, Optional, Sequence
 
+import time
+
 import numpy as np
 
 from .transforms import transform2Dto3D_batch, transform2Dto3D, transform3Dto2D
@@ -78,6 +80,8 @@ class LoopDetector:
         self.filter_on_device = bool(filter_on_device)   # find_candidates through dgs_find_loop_candidates (second half)
         self._cloud_cache = {}
         self._exchange_buffers = {}
+        self.exchange_seconds = 0.0   # host time spent in the exchange step (all-gather of the result records) since construction
+        self.exchange_calls = 0
         self.force_exchange = False   # measurement: run the exchange step even when the group has one rank (its floor: two copies + one collective)
 
     def resident(self, keyframe: "KeyFrame", as_target: bool = False):
@@ -180,7 +184,10 @@ class LoopDetector:
         if world == 1 and not self.force_exchange:
             allrec = rec
         else:
+            t_ex = time.perf_counter()
             allrec = self._exchange(rec, per_rank, world)
+            self.exchange_seconds += time.perf_counter() - t_ex   # the path's one exchange step, as the host sees it (bench.py reports it per rank)
+            self.exchange_calls += 1
         out = np.full((n, RECORD_WIDTH), -1.0, dtype=np.float64)
         idx = allrec[:, 0].astype(np.int64)
         ok = (idx >= 0) & (idx < n)          # padding rows of the gather carry -1

@@ -508,6 +508,11 @@ class RegistrationGroup:
         return bool(self._lib.dgs_group_uses_rccl(self._g))
 
     @property
+    def rccl_ranks(self) -> int:
+        """ncclCommCount of the group's communicator (0 without RCCL)."""
+        return int(self._lib.dgs_group_rccl_ranks(self._g))
+
+    @property
     def last_gather_used_rccl(self) -> bool:
         return bool(self._lib.dgs_group_last_gather_used_rccl(self._g))
 

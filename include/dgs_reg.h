@@ -266,6 +266,7 @@ void dgs_group_destroy(dgs_group* g);
 const char* dgs_group_last_error(const dgs_group* g);
 int32_t dgs_group_size(const dgs_group* g);
 int32_t dgs_group_uses_rccl(const dgs_group* g);               /* 1: the group holds RCCL communicators */
+int32_t dgs_group_rccl_ranks(const dgs_group* g);              /* ncclCommCount of the group's communicator (0: no RCCL) */
 int32_t dgs_group_last_gather_used_rccl(const dgs_group* g);   /* 1: the last dgs_group_align_batch exchanged its records with ncclAllGather */
 dgs_handle* dgs_group_member(dgs_group* g, int32_t k);         /* member k's handle (e.g. for dgs_profile_*); owned by the group */
 int dgs_group_set_input_target(dgs_group* g, const float* xyz16, int64_t n);
