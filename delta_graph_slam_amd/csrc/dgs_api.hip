@@ -310,6 +310,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (kExperiments)   // the product library carries neither the grid index nor the packed-FP32 kernel (measured losers: `make experiments`)
     if (const char* e = std::getenv("DGS_NN_GRID")) { h->grid_mode = std::atoi(e); h->grid_levels = std::max(1, std::atoi(e)); }
   if (const char* e = std::getenv("DGS_NDT_FUSED")) h->ndt_fused = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NDT_STRICT_KERNEL")) h->strict_kernel = std::atoi(e) == 2 ? 2 : 3;
   if (const char* e = std::getenv("DGS_NDT_HD_OVERLAP")) h->hd_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NDT_SOLVE_MIN_ACTIVE")) h->solve_min_active = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("DGS_NDT_QUEUE")) h->ndt_queue_mode = std::atoi(e);

@@ -114,6 +114,7 @@ struct dgs_handle {
   hipStream_t hd_stream = nullptr;
   static constexpr int kHdEvents = 32;
   hipEvent_t ev_hd_a[kHdEvents] = {}, ev_hd_b[kHdEvents] = {};
+  int strict_kernel = 3;              // DGS_NDT_STRICT_KERNEL: upstream-order kernels: 3 item-compacted (one launch per round), 2 lane-per-point (two launches per round)
   bool hd_overlap = true;             // DGS_NDT_HD_OVERLAP=0: the computeHessian launch of a round in line with the round's first launch
   int solve_min_active = 0;           // DGS_NDT_SOLVE_MIN_ACTIVE (default 0 = the Newton step stays in the closing workgroup): item-compacted upstream-order kernel:
                                       // with at least this many pairs in a launch the Newton steps go to ndt_strict_solve_kernel on the third stream.  Measured on the

@@ -93,7 +93,7 @@ struct NdtHdrRegs {
   __device__ __forceinline__ float H(int k, int c) const { return h[k * 3 + c]; }
 };
 
-// exp(x) for the default evaluation order: v_exp_f32 of x * log2(e) with the product's rounding error (and the low bits of log2 e)
+// (A/B builds only since round 4, see ndt_point_loop.)  exp(x) for the default evaluation order: v_exp_f32 of x * log2(e) with the product's rounding error (and the low bits of log2 e)
 // folded back in -- within ~1 ulp of the exact value for every x whose result is a normal float, 0 / inf beyond, NaN for NaN --
 // in 6 instructions where the library expf takes 14 (its range reduction + ldexp buy correct subnormal results, which the NDT
 // weights never need: such a term is < 1e-38 of the sum).  The validation orders use det_expf (common.h).
@@ -147,6 +147,9 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
 
     // ---- fold the neighbourhood:  A = sum w C,  b = sum w C q,  M = sum w d2 (Cq)(Cq)^T,  score
     float N[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, sc = 0.f;   // N = A - M, accumulated directly
+#if defined(DGS_FAST_AM) && DGS_FAST_AM == 1
+    float Mm[6] = {0, 0, 0, 0, 0, 0};
+#endif
     bool any = false;
 #pragma unroll
     for (int k = 0; k < NB; k++) {
@@ -167,7 +170,17 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
       const float u0 = q0 * Cxx + q1 * Cxy + q2 * Cxz;
       const float u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
       const float u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
+      // The library expf (<= 1 ulp).  Round 3 had put a 6-instruction hardware form here (exp_hw, <= 2 ulp; 2 % of the step): on the bench shard it
+      // moved pair 20 of seed 40 to another optimum, 0.945 m from the reference's and outside the reference's own 34-twin band (0.872 m) --
+      // isolated in round 4 with A/B builds (make variants, scripts/r4_fast_variants.py, profiles/r04/fast_order_variants.jsonl: the pair is
+      // back inside the gate with expf or det_expf, whichever way N is accumulated) and reverted.  DGS_FAST_EXP=0 / 2 build the other two.
+#if defined(DGS_FAST_EXP) && DGS_FAST_EXP == 0
       float e = exp_hw(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
+#elif defined(DGS_FAST_EXP) && DGS_FAST_EXP == 2
+      float e = det_expf(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
+#else
+      float e = expf(-gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f);
+#endif
       // gauss_d1 is a double upstream: float(double(e) * d1), not e * float(d1) -- the float constant alone would scale score,
       // gradient and Hessian by (1 + 2.8e-8) at 1 m resolution, which was the whole per-evaluation difference to a CPU run
       const float score_inc = (float)(-gd1 * (double)e);
@@ -179,8 +192,13 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
       b[0] += w * u0; b[1] += w * u1; b[2] += w * u2;
       if (need_h) {   // a score + gradient evaluation (a More-Thuente trial) needs neither A nor M: wave-uniform, a scalar branch
         const float wd = w * gd2, t0 = wd * u0, t1 = wd * u1, t2 = wd * u2;
+#if defined(DGS_FAST_AM) && DGS_FAST_AM == 1   // A/B build: A and M accumulated apart, N = A - M once per point (round 2's form)
+        N[0] += w * Cxx; N[1] += w * Cxy; N[2] += w * Cxz; N[3] += w * Cyy; N[4] += w * Cyz; N[5] += w * Czz;
+        Mm[0] += t0 * u0; Mm[1] += t0 * u1; Mm[2] += t0 * u2; Mm[3] += t1 * u1; Mm[4] += t1 * u2; Mm[5] += t2 * u2;
+#else
         N[0] += w * Cxx; N[1] += w * Cxy; N[2] += w * Cxz; N[3] += w * Cyy; N[4] += w * Cyz; N[5] += w * Czz;
         N[0] -= t0 * u0; N[1] -= t0 * u1; N[2] -= t0 * u2; N[3] -= t1 * u1; N[4] -= t1 * u2; N[5] -= t2 * u2;
+#endif
       }
     }
     if (!any) continue;
@@ -205,7 +223,11 @@ __device__ __forceinline__ void ndt_point_loop(const float (&T)[12], const HDR& 
     acc[5] += (double)(b[0] * J4[0] + b[1] * J4[1] + b[2] * J4[2]);
     acc[6] += (double)(b[0] * J5[0] + b[1] * J5[1] + b[2] * J5[2]);
     if (need_h) {
+#if defined(DGS_FAST_AM) && DGS_FAST_AM == 1
+      const float N0 = N[0] - Mm[0], N1 = N[1] - Mm[1], N2 = N[2] - Mm[2], N3 = N[3] - Mm[3], N4 = N[4] - Mm[4], N5 = N[5] - Mm[5];
+#else
       const float N0 = N[0], N1 = N[1], N2 = N[2], N3 = N[3], N4 = N[4], N5 = N[5];
+#endif
       // N * J_k
       const float n3[3] = {N1 * J3[1] + N2 * J3[2], N3 * J3[1] + N4 * J3[2], N4 * J3[1] + N5 * J3[2]};
       const float n4[3] = {N0 * J4[0] + N1 * J4[1] + N2 * J4[2], N1 * J4[0] + N3 * J4[1] + N4 * J4[2], N2 * J4[0] + N4 * J4[1] + N5 * J4[2]};
@@ -1756,24 +1778,22 @@ static void launch_strict_rows(dgs_handle* h, const NdtLaunch& L, const dim3 gri
 
 // ndt_strict_order 1: ndt_strict_kernel (ndt_strict.h); launch >= 0: fused (derivatives + closing workgroups), < 0: derivatives only.
 // hd: the instantiation for the pairs waiting for the double-precision computeHessian pass (evaluation kind 2).
-// DGS_NDT_STRICT_KERNEL=2: the lane-per-point kernels (two launches per round); default 3: the item-compacted kernel (one launch per round)
+// dgs_handle::strict_kernel (DGS_NDT_STRICT_KERNEL at dgs_create): 3 (default) the item-compacted kernel, one launch per round; 2 the
+// lane-per-point kernels, two launches per round.
 // (Measured and dropped: the item-compacted kernel for the float kinds alone -- 64-point tiles, a third of the LDS, meant for three waves
 // per SIMD -- with the lane-per-point computeHessian kernel as the round's second launch: the register allocator spilled the double
 // accumulators, 47 ms per step.)
-static int strict_kernel_version() {
-  static const int v = std::getenv("DGS_NDT_STRICT_KERNEL") ? std::atoi(std::getenv("DGS_NDT_STRICT_KERNEL")) : 3;
-  return v == 2 ? 2 : 3;
-}
+static int strict_kernel_version(const dgs_handle* h) { return h->strict_kernel == 2 ? 2 : 3; }
 
 // item-compacted kernel, fused launches: the Newton steps of the closings go to ndt_strict_solve_kernel on the third stream
 static bool strict_solve_beside(const dgs_handle* h) {
-  return strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25) && h->ndt_fused && h->solve_min_active > 0 && h->hd_stream != nullptr &&
+  return strict_kernel_version(h) == 3 && h->n_occupied_bound < (1 << 25) && h->ndt_fused && h->solve_min_active > 0 && h->hd_stream != nullptr &&
          h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM;
 }
 
 template <int SEARCH>
 static void launch_strict_sums(dgs_handle* h, const NdtLaunch& L, const dim3 grid, const int leaf_pow2, const int launch, const bool hd) {
-  if (strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25)) {
+  if (strict_kernel_version(h) == 3 && h->n_occupied_bound < (1 << 25)) {
     if (hd && launch >= 0) return;   // one kernel serves every kind (launch < 0: the test hook asks for the kind it has set up)
     if (launch >= 0)
       hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
@@ -2075,7 +2095,7 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
         Lr.total_blocks = n_pairs * Lr.cap_blocks;
       }
       round_no++;
-      const bool two_kinds = h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM && h->consts.hessian_double && !(strict_kernel_version() == 3 && h->n_occupied_bound < (1 << 25));   // ndt_strict.h, lane-per-point kernels: kinds 0 / 1, then kind 2
+      const bool two_kinds = h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM && h->consts.hessian_double && !(strict_kernel_version(h) == 3 && h->n_occupied_bound < (1 << 25));   // ndt_strict.h, lane-per-point kernels: kinds 0 / 1, then kind 2
       if (fused) {
         if (two_kinds && h->hd_overlap && h->hd_stream) {
           // round r: [main] first kernel, [computeHessian stream] second kernel beside the first kernel of round r + 1; the first kernel of

@@ -120,7 +120,15 @@ void orc_jsvd_solve6(const double* A, const double* b, double* x, int32_t* sr) {
   if (sr) { sr[0] = st.sweeps; sr[1] = st.rotations; }
 }
 void orc_affine_rotation_f32(const float* T16, float* R9) { affine_rotation_f32(T16, R9); }
-void orc_ndt_hessian_double(void* h, const double* p6, double* H36) { static_cast<NdtCpu*>(h)->hessian_double(p6, H36); }
+void orc_ndt_hessian_double(void* h, const double* p6, double* H36) {
+  NdtCpu* n = static_cast<NdtCpu*>(h);
+  const double c1 = 10.0 * (1.0 - n->prm.outlier_ratio);   // as orc_ndt_derivatives: single evaluations are self-contained
+  const double c2 = n->prm.outlier_ratio / std::pow(n->prm.resolution, 3);
+  const double d3 = -std::log(c2);
+  n->gauss_d1 = -std::log(c1 + c2) - d3;
+  n->gauss_d2 = -2.0 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / n->gauss_d1);
+  n->hessian_double(p6, H36);
+}
 double orc_det_exp(double x) { return det_exp(x); }
 void orc_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); }
 void orc_sym_eig3(const double* A, double* ev, double* V) { sym_eig3(A, ev, V); }

@@ -7,6 +7,11 @@ import pytest
 
 from delta_graph_slam_amd import synth
 
+# test_cfg4_at_its_full_candidate_count...: measured on an MI355X with the round-4 upstream-order kernel (item-compacted, one launch per round)
+CFG4_OTHER_EVALUATION_COUNT = [24, 225]   # candidates of the 256 whose evaluation count (or transform) differs from the oracle's
+CFG4_ONE_ULP_TRANSFORMS = []              # ... of which: one float of the transform one ulp off
+CFG4_ONE_ULP_TRANSFORMS_HOST_DEALING = [] # the same batch dealt candidate c -> member c mod 8 (another partition of the sums)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -222,7 +227,10 @@ def test_cfg4_at_its_full_candidate_count_256_candidates_over_8_members(oracle_l
         # transform, 1 with a one-ulp float; 0 of either kind on the 96 pairs of the three bench shards) -- never more
         assert np.abs(res[c]["T"].astype(np.float64) - ref[c]["T"]).max() <= 1.2e-7 * max(1.0, np.abs(ref[c]["T"]).max()), c
         assert abs(res[c]["fitness"] - fit_ref[c]) <= 1e-9 * fit_ref[c], c
-    assert len(off) <= 24 and sum(not np.array_equal(res[c]["T"], ref[c]["T"]) for c in off) <= 3, off
+    # Round 3 asserted "at most 24 / at most 3"; the measurement itself is the assertion now (round-4 kernels, 8 members of 32 pairs): WHICH
+    # candidates took another number of evaluations, and which of them ended one float ulp off.  A kernel change that moves a pair shows here.
+    unequal = [c for c in off if not np.array_equal(res[c]["T"], ref[c]["T"])]
+    assert (off, unequal) == (CFG4_OTHER_EVALUATION_COUNT, CFG4_ONE_ULP_TRANSFORMS), (off, unequal)
     assert g.best_index == b_ref and abs(g.best_score - s_ref) <= 1e-9 * s_ref
     # ... and on exactly those pairs index-order sums (ndt_strict_order = 2: every evaluation bit-identical to the CPU's) give the very
     # transform, iteration and evaluation counts of the reference loop
@@ -243,7 +251,7 @@ def test_cfg4_at_its_full_candidate_count_256_candidates_over_8_members(oracle_l
         assert res2[c]["iterations"] == ref[c]["iterations"] and res2[c]["converged"] == ref[c]["converged"], c
         assert np.abs(res2[c]["T"].astype(np.float64) - ref[c]["T"]).max() <= 1.2e-7 * max(1.0, np.abs(ref[c]["T"]).max()), c
         assert abs(res2[c]["fitness"] - fit_ref[c]) <= 1e-9 * fit_ref[c], c
-    assert sum(not np.array_equal(res2[c]["T"], ref[c]["T"]) for c in range(N)) <= 3
+    assert [c for c in range(N) if not np.array_equal(res2[c]["T"], ref[c]["T"])] == CFG4_ONE_ULP_TRANSFORMS_HOST_DEALING
     last = N + pad
     assert last % 8 == b_ref % 8
     assert np.array_equal(res2[last]["T"], res2[b_ref]["T"]) and res2[last]["fitness"] == res2[b_ref]["fitness"]

@@ -1,0 +1,113 @@
+"""CPU pins of round 4's oracle pieces (oracle/cpu/linalg.hpp, ndt_cpu.cpp): the restatements of Eigen::JacobiSVD<Matrix6d>::solve (two-sided
+Jacobi), Eigen::Affine3f::rotation() (polar factor through a float JacobiSVD), PCL's double-precision computeHessian / updateHessian and
+det_exp -- against numpy / scipy and against the float pass they replace.  (Parity with upstream itself stays unpinned: DESIGN.md 2.)"""
+import math
+
+import numpy as np
+import pytest
+
+from delta_graph_slam_amd import synth
+from oracle import oracle as orc
+
+
+def test_jsvd_solve_matches_numpy_on_regular_symmetric_nonsymmetric_and_singular_systems():
+    rng = np.random.default_rng(7)
+    worst = 0.0
+    for it in range(200):
+        A = rng.normal(size=(6, 6))
+        if it % 2 == 0:
+            A = A + A.T
+        if it % 5 == 0:
+            A *= 10.0 ** rng.integers(-6, 7)          # Eigen scales the work matrix by max|A|: the answer must not care
+        b = rng.normal(size=6)
+        x, sweeps, rotations = orc.jsvd_solve6(A, b, stats=True)
+        ref = np.linalg.solve(A, b)
+        worst = max(worst, np.abs(x - ref).max() / np.abs(ref).max())
+        assert 1 <= sweeps <= 12 and rotations <= 15 * sweeps
+    assert worst < 1e-10
+    # rank-deficient: the minimum-norm least-squares solution, the rank decided by Eigen's threshold (6 eps s_max)
+    A = rng.normal(size=(6, 3))
+    A = A @ A.T
+    b = rng.normal(size=6)
+    assert np.allclose(orc.jsvd_solve6(A, b), np.linalg.pinv(A) @ b, atol=1e-12)
+    assert np.allclose(orc.jsvd_solve6(np.diag([3.0, 2.0, 1.0, 0.0, 0.0, 0.0]), np.arange(1.0, 7.0)), [1 / 3, 1.0, 3.0, 0, 0, 0], atol=1e-15)
+    assert np.array_equal(orc.jsvd_solve6(np.zeros((6, 6)), b), np.zeros(6))
+    # a diagonal matrix takes no rotation at all: one sweep that finds every block diagonal, the solve is exact
+    x, sweeps, rotations = orc.jsvd_solve6(np.diag([4.0, -2.0, 1.0, 8.0, 0.5, -16.0]), np.ones(6), stats=True)
+    assert (sweeps, rotations) == (1, 0) and np.array_equal(x, [0.25, -0.5, 1.0, 0.125, 2.0, -0.0625])
+
+
+def test_jsvd_agrees_with_the_one_sided_stand_in_on_ndt_hessians():
+    tgt, src, _ = synth.planar_pair(n=8192)
+    o = orc.NdtOracle(resolution=1.0)
+    o.set_target(tgt)
+    o.set_source(src)
+    for p in ([0, 0, 0, 0, 0, 0], [0.2, -0.05, 0.03, 0.02, -0.03, 0.04]):
+        _, g, H = o.derivatives(np.array(p, float))
+        a, sweeps, _ = orc.jsvd_solve6(H, -g, stats=True)
+        b = orc.svd_solve6(H, -g)
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max() and sweeps <= 8
+
+
+def test_affine_rotation_is_the_polar_factor():
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        R = Rotation.from_euler("xyz", rng.uniform(-1, 1, 3)).as_matrix()
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = R.astype(np.float32)
+        assert np.abs(orc.affine_rotation_f32(T) - T[:3, :3]).max() <= 1e-6          # a rotation is its own polar factor (to the float rounding of a 3 x 3 SVD)
+        M = R @ np.diag(rng.uniform(0.9, 1.1, 3)) + rng.normal(scale=1e-3, size=(3, 3))
+        T[:3, :3] = M.astype(np.float32)
+        U, _, Vt = np.linalg.svd(T[:3, :3].astype(np.float64))
+        assert np.abs(orc.affine_rotation_f32(T) - U @ Vt).max() <= 2e-6
+    assert np.array_equal(orc.affine_rotation_f32(np.eye(4, dtype=np.float32)), np.eye(3, dtype=np.float32))
+
+
+def test_det_exp_is_exp_to_two_ulps():
+    for x in np.concatenate([np.linspace(-50, 5, 401), [-700.0, -745.0, 0.0, 1e-300, 709.0]]):
+        a, b = orc.det_exp(float(x)), math.exp(float(x))
+        assert abs(a - b) <= 5e-16 * b + 5e-324, (x, a, b)
+    assert orc.det_exp(-800.0) == 0.0 and math.isinf(orc.det_exp(800.0)) and math.isnan(orc.det_exp(float("nan")))
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "KDTREE"])
+def test_double_compute_hessian_is_the_float_hessian_to_float_rounding(search):
+    """PCL's computeHessian in double against updateDerivatives' float Hessian at the same pose: the same quantity, 6e-8 apart (float
+    rounding of the per-point terms) -- and symmetric to double rounding, which the float one is not."""
+    tgt, src, _ = synth.planar_pair(n=8192)
+    o = orc.NdtOracle(resolution=1.0, search_method=search)
+    o.set_target(tgt)
+    o.set_source(src)
+    for p in ([0.2, -0.05, 0.03, 0.02, -0.03, 0.04], [1.0, 0.5, 0.1, 0.1, -0.1, 0.3]):
+        p = np.array(p, float)
+        _, _, H = o.derivatives(p)
+        Hd = o.hessian_double(p)
+        assert np.abs(H - Hd).max() <= 2e-6 * np.abs(H).max()
+        assert np.abs(Hd - Hd.T).max() <= 1e-12 * np.abs(Hd).max()
+
+
+def test_each_switch_changes_the_run_it_governs_and_only_by_rounding():
+    tgt, src, Tgt = synth.planar_pair(n=8192)
+    guess = Tgt.copy().astype(np.float32)
+    guess[0, 3] -= 0.2
+    base = dict(newton_solver=0, hessian_recompute_double=0, guess_rotation_polar=0)
+    runs = {}
+    for name in ("none", "newton_solver", "hessian_recompute_double", "guess_rotation_polar", "all"):
+        kw = dict(base)
+        if name == "all":
+            kw = {}
+        elif name != "none":
+            kw[name] = 1
+        o = orc.NdtOracle(resolution=1.0, **kw)
+        o.set_target(tgt)
+        o.set_source(src)
+        runs[name] = o.align(guess)
+    from tests.helpers import pose_error
+    for name, r in runs.items():
+        assert r["converged"]
+        dt, dr = pose_error(r["T"], runs["none"]["T"])
+        assert dt < 5e-3 and dr < 5e-4, (name, dt, dr)       # same optimum
+    # the polar factor moves the initial pose vector by float rounding of the rotation block, the others leave it alone
+    assert np.array_equal(runs["newton_solver"]["trajectory"][0], runs["none"]["trajectory"][0])
+    assert np.abs(runs["guess_rotation_polar"]["trajectory"][0] - runs["none"]["trajectory"][0]).max() <= 1e-6

@@ -1,0 +1,143 @@
+"""-m gpu: round 4's upstream-order path against the CPU oracle.
+
+  * the three fidelity switches (dgs_params.ndt_newton_solver / ndt_hessian_recompute_double / ndt_guess_rotation_polar), each alone and all
+    together, in ndt_strict_order 2 (every evaluation, the trajectory and the transform bit-identical) and 1 (transform bit-equal);
+  * the double-precision computeHessian pass as a single evaluation (dgs_ndt_hessian_double): bit-identical sums in order 2, 1e-11 in order 1;
+  * the launch structures of order 1 -- item-compacted kernel (default), lane-per-point kernels with the computeHessian launch in line or on its
+    own stream, Newton steps in the closing workgroup or in ndt_strict_solve_kernel on the third stream, fused / unfused -- all give the
+    SAME transforms, iteration and evaluation counts as the oracle on a batch whose pairs finish at different rounds;
+  * the Newton step through the wave-parallel two-sided Jacobi SVD equals the oracle's restatement of Eigen's: checked through the first
+    iterate of a registration (p0 + a * dir with dir from the solve), bit for bit, on Hessians of three scenes."""
+import os
+
+import numpy as np
+import pytest
+
+from delta_graph_slam_amd import _lib as L
+from delta_graph_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SW = ("ndt_newton_solver", "ndt_hessian_recompute_double", "ndt_guess_rotation_polar")
+OSW = ("newton_solver", "hessian_recompute_double", "guess_rotation_polar")
+
+
+def _reg(**kw):
+    from delta_graph_slam_amd.registration import Registration
+    kw.setdefault("ndt_resolution", 1.0)
+    return Registration("NDT_OMP", **kw)
+
+
+def _env(**kv):
+    class E:
+        def __enter__(self):
+            self.old = {k: os.environ.get(k) for k in kv}
+            os.environ.update({k: str(v) for k, v in kv.items()})
+
+        def __exit__(self, *a):
+            for k, v in self.old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return E()
+
+
+@pytest.mark.parametrize("on", [(), (0,), (1,), (2,), (0, 1, 2)])
+def test_switches_alone_and_together_against_the_oracle_with_the_same_switches(oracle_lib, on):
+    tgt, src, Tgt = synth.kitti_pair(n_points=32768)
+    guess = Tgt.copy().astype(np.float32)
+    guess[0, 3] -= 0.25
+    guess[1, 3] += 0.10
+    dkw = {SW[k]: int(k in on) for k in range(3)}
+    okw = {OSW[k]: int(k in on) for k in range(3)}
+    o = oracle_lib.NdtOracle(resolution=1.0, **okw)
+    o.set_target(tgt)
+    o.set_source(src)
+    ro = o.align(guess)
+    assert ro["converged"] and ro["hessian_recomputes"] >= 1, "the case must exercise the closing computeHessian"
+    for order in (2, 1):
+        r = _reg(ndt_strict_order=order, **dkw)
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        r.align(guess)
+        assert r.hasConverged() and (r.last_result.iterations, r.last_result.evaluations) == (ro["iterations"], ro["evaluations"]), (order, on)
+        assert np.array_equal(r.getFinalTransformation(), ro["T"]), (order, on)
+        t = r.ndt_trajectory()
+        assert t.shape == ro["trajectory"].shape
+        assert np.array_equal(t[0], ro["trajectory"][0]), "the initial pose vector (Euler angles of the guess / of its polar factor) is host arithmetic: exact"
+        if order == 2:
+            assert np.array_equal(t, ro["trajectory"]), on
+        else:
+            assert np.abs(t - ro["trajectory"]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("search", ["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"])
+def test_double_compute_hessian_evaluation(oracle_lib, search):
+    tgt, src, _ = synth.planar_pair(n=16384)
+    o = oracle_lib.NdtOracle(resolution=1.0, search_method=search)
+    o.set_target(tgt)
+    o.set_source(src)
+    regs = {m: _reg(ndt_strict_order=m, ndt_search_method=L.NDT_SEARCH[search]) for m in (1, 2)}
+    with _env(DGS_NDT_STRICT_KERNEL=2):
+        regs["lane-per-point"] = _reg(ndt_strict_order=1, ndt_search_method=L.NDT_SEARCH[search])
+    for r in regs.values():
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+    for p in ([0.2, -0.05, 0.03, 0.02, -0.03, 0.04], [5.0, 3.0, 0.5, 0.3, -0.2, 1.0]):
+        p = np.array(p, float)
+        Hd = o.hessian_double(p)
+        assert np.array_equal(regs[2].ndt_hessian_double(p), Hd), (search, p)
+        for k in (1, "lane-per-point"):
+            assert np.abs(regs[k].ndt_hessian_double(p) - Hd).max() <= 1e-11 * np.abs(Hd).max(), (search, k)
+    from delta_graph_slam_amd.registration import DgsError
+    f = _reg(ndt_strict_order=0)
+    f.setInputTarget(tgt)
+    f.setInputSource(src)
+    with pytest.raises(DgsError):      # the default order has no double pass: DGS_ERR_UNSUPPORTED, never a silent float answer
+        f.ndt_hessian_double(np.zeros(6))
+
+
+def test_every_launch_structure_of_the_upstream_order_gives_the_oracles_runs(oracle_lib):
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=12, n_points=16384, seed=40, distinct_scans=12)
+    o = oracle_lib.NdtOracle(resolution=1.0)
+    o.set_target(tgt)
+    ref = []
+    for c in range(12):
+        o.set_source(sources[c])
+        ref.append(o.align(guesses[c]))
+    assert len({r["evaluations"] for r in ref}) >= 4 and sum(r["hessian_recomputes"] for r in ref) >= 6
+    variants = {"item-compacted (default)": {}, "Newton steps on the third stream": dict(DGS_NDT_SOLVE_MIN_ACTIVE=2),
+                "lane-per-point, computeHessian beside": dict(DGS_NDT_STRICT_KERNEL=2), "lane-per-point, in line": dict(DGS_NDT_STRICT_KERNEL=2, DGS_NDT_HD_OVERLAP=0),
+                "item-compacted, unfused": dict(DGS_NDT_FUSED=0), "lane-per-point, unfused": dict(DGS_NDT_STRICT_KERNEL=2, DGS_NDT_FUSED=0)}
+    for name, env in variants.items():
+        with _env(**env):
+            r = _reg(ndt_strict_order=1)
+        r.setInputTarget(tgt)
+        for rep in range(2):      # twice: the second batch re-uses every buffer, stream and event of the first
+            res = r.align_batch(sources, guesses, compute_fitness=False)
+            for c in range(12):
+                assert res[c]["converged"] == ref[c]["converged"] and res[c]["iterations"] == ref[c]["iterations"], (name, c)
+                assert res[c]["evaluations"] == ref[c]["evaluations"], (name, c, res[c]["evaluations"], ref[c]["evaluations"])
+                assert np.array_equal(res[c]["T"], ref[c]["T"]), (name, c)
+        r.close()
+
+
+@pytest.mark.parametrize("scene", ["planar", "kitti", "indoor"])
+def test_wave_parallel_jacobi_svd_step_is_the_oracles(oracle_lib, scene):
+    """Order 2 makes (score, gradient, Hessian) bit-identical, so the first iterate p1 = p0 + a * dir is equal to the oracle's iff the
+    Newton direction -- JacobiSVD(H).solve(-g) across one wave -- is, bit for bit; for both solvers."""
+    tgt, src, _ = {"planar": lambda: synth.planar_pair(n=16384), "kitti": lambda: synth.kitti_pair(n_points=32768),
+                   "indoor": lambda: synth.indoor_pair(n=32768)}[scene]()
+    res = 0.5 if scene == "indoor" else 1.0
+    for solver in (1, 0):
+        o = oracle_lib.NdtOracle(resolution=res, newton_solver=solver, max_iterations=2)
+        o.set_target(tgt)
+        o.set_source(src)
+        ro = o.align()
+        r = _reg(ndt_strict_order=2, ndt_resolution=res, ndt_newton_solver=solver, maximum_iterations=2)
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        r.align()
+        t = r.ndt_trajectory()
+        assert len(t) >= 2 and np.array_equal(t[:3], ro["trajectory"][:3]), (scene, solver)
