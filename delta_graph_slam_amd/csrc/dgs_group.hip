@@ -186,75 +186,6 @@ bool ensure_buffers(dgs_group* g, size_t per_member) {
   return true;
 }
 
-// One thread per candidate of a member's share: the exchange record, written ON THE DEVICE from the optimiser state and the
-// fitness sums the member's kernels left in HBM -- what loop_detector.hpp:145-155 reads per candidate.  Mirrors what
-// dgs_align_batch reports on the host bit for bit (fitness = sum / count in double, DBL_MAX without a qualifying point; an empty
-// source is "not converged, transformation = guess", scan_matching_odometry_nodelet.cpp:222-226).
-__global__ void group_record_kernel(const int method, const dgs::NdtPair* __restrict__ npairs, const int* __restrict__ nsizes,
-                                    const dgs::GicpPair* __restrict__ gpairs, const dgs::GicpItem* __restrict__ gitems,
-                                    const double* __restrict__ nn_out, const int compute_fitness, const int* __restrict__ cand,
-                                    const float* __restrict__ guesses, const int m, char* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  Record r;
-  r.pad = 0;
-  r.candidate = cand[i];
-  r.status = DGS_OK;
-  const float* Tsrc;
-  int size;
-  if (method == DGS_METHOD_NDT) {
-    const dgs::NdtPair& p = npairs[i];
-    size = nsizes[i];
-    Tsrc = p.final_T;
-    r.converged = (p.s.phase == dgs::PH_DONE) ? p.s.converged : 0;
-    r.iterations = p.s.nr_iterations;
-    r.evaluations = p.s.evaluations;
-    r.score = p.s.score;
-  } else {
-    const dgs::GicpPair& p = gpairs[i];
-    size = gitems[i].n;
-    Tsrc = p.final_T;
-    r.converged = (p.s.phase == dgs::GP_DONE) ? p.s.converged : 0;
-    r.iterations = p.s.iteration;
-    r.evaluations = p.s.evaluations;
-    r.score = p.s.y0;
-  }
-  r.fitness = __builtin_nan("");
-  if (compute_fitness) {
-    const double sum = nn_out[i * 4 + 0], cnt = nn_out[i * 4 + 1];
-    r.fitness = cnt > 0 ? sum / cnt : DBL_MAX;
-  }
-  if (size <= 0) {   // PCL refuses an empty source: not converged, transform = guess
-    Tsrc = guesses + 16 * (size_t)i;
-    r.converged = 0; r.iterations = 0; r.evaluations = 0; r.status = DGS_ERR_NO_SOURCE;
-    r.score = 0.0; r.fitness = __builtin_nan("");
-  }
-  for (int k = 0; k < 16; k++) r.T[k] = Tsrc[k];
-  *reinterpret_cast<Record*>(out + (size_t)i * kRecordBytes) = r;
-}
-
-// Runs on member k's worker thread right after its batch: staging (candidate numbers, guesses) up, records written by the device
-// into d_send[k] on the member's stream.  Nothing the all-gather sends has been on the host.
-bool enqueue_records(dgs_group* g, int k, const std::vector<int>& ids, const float* guesses_of_member, int per, int compute_fitness) {
-  dgs_handle* h = g->members[k];
-  const int m = (int)ids.size();
-  if (hipSetDevice(g->devices[k]) != hipSuccess) return false;
-  if (hipMemsetAsync(g->d_send[k], 0xFF, (size_t)per * kRecordBytes, h->stream) != hipSuccess) return false;   // candidate = -1: padding rows
-  if (m == 0) return true;
-  char* hs = static_cast<char*>(g->h_stage[k]);
-  std::memcpy(hs, ids.data(), sizeof(int) * m);
-  const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  float* hg = reinterpret_cast<float*>(hs + sizeof(int) * (size_t)per);
-  for (int j = 0; j < m; j++) std::memcpy(hg + 16 * (size_t)j, guesses_of_member ? guesses_of_member + 16 * (size_t)j : ident, sizeof(float) * 16);
-  if (hipMemcpyAsync(g->d_stage[k], hs, sizeof(int) * (size_t)per + 64 * (size_t)m, hipMemcpyHostToDevice, h->stream) != hipSuccess) return false;
-  const char* ds = static_cast<const char*>(g->d_stage[k]);
-  const bool ndt = h->prm.method == DGS_METHOD_NDT;
-  hipLaunchKernelGGL(group_record_kernel, dim3((m + 63) / 64), dim3(64), 0, h->stream, (int)h->prm.method, ndt ? h->pairs.ptr : nullptr,
-                     ndt ? h->src_sizes.ptr : nullptr, ndt ? nullptr : h->gpairs.ptr, ndt ? nullptr : h->gitems.ptr, h->nn_out, compute_fitness,
-                     reinterpret_cast<const int*>(ds), reinterpret_cast<const float*>(ds + sizeof(int) * (size_t)per), m, static_cast<char*>(g->d_send[k]));
-  return hipGetLastError() == hipSuccess;
-}
-
 void fail_share(std::vector<dgs_result>& res, const float* gs, int rc) {
   const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   for (size_t j = 0; j < res.size(); j++) {
@@ -273,7 +204,6 @@ int run_dealt_batch(dgs_group* g, int n, const std::vector<std::vector<int>>& id
   std::vector<std::vector<float>> gs(G);
   std::vector<std::vector<dgs_result>> res(G);
   std::vector<int> rcs(G, DGS_OK);
-  std::vector<char> dev_ok(G, 0);
   for (int k = 0; k < G; k++) {
     res[k].resize(ids[k].size());
     if (guesses16)
@@ -282,11 +212,10 @@ int run_dealt_batch(dgs_group* g, int n, const std::vector<std::vector<int>>& id
   const bool have_buffers = ensure_buffers(g, (size_t)per);
   // ---- every member registers its share as one batch on its own thread / stream, then writes its records on the device
   for (int k = 0; k < G; k++) {
-    auto job = [g, k, per, have_buffers, compute_fitness, guesses16, &ids, &gs, &res, &rcs, &dev_ok, &run] {
+    auto job = [k, guesses16, &ids, &gs, &res, &rcs, &run] {
       const float* gk = guesses16 ? gs[k].data() : nullptr;
       if (!ids[k].empty()) rcs[k] = run(k, gk, res[k].data());
       if (rcs[k] != DGS_OK) fail_share(res[k], gk, rcs[k]);   // reported per candidate as "not converged" (the reference skips them, loop_detector.hpp:149)
-      if (have_buffers && rcs[k] == DGS_OK) dev_ok[k] = enqueue_records(g, k, ids[k], gk, per, compute_fitness) ? 1 : 0;
     };
     if (g->workers[k]) g->workers[k]->submit(job); else job();
   }
@@ -294,7 +223,10 @@ int run_dealt_batch(dgs_group* g, int n, const std::vector<std::vector<int>>& id
     if (g->workers[k]) g->workers[k]->wait();
   for (int k = 0; k < G; k++)
     if (rcs[k] != DGS_OK) g->err = "member " + std::to_string(k) + " (device " + std::to_string(g->devices[k]) + "): " + dgs_last_error(g->members[k]);
-  // a member whose batch (or record launch) failed sends host-made records instead: the collective still needs its contribution
+  // Every member's records are made from the result array its batch call filled anyway (dgs_align_batch ends with one synchronisation and
+  // the results on the host): 128 bytes per candidate, staged through pinned memory into the all-gather.  (Round 3 rebuilt the same
+  // records on the device with a kernel of its own behind that synchronisation -- a memset, a copy and a launch that bought nothing.)  A
+  // member whose batch failed contributes "failed" records: the collective still needs its contribution.
   std::vector<Record> all((size_t)G * per);
   for (auto& r : all) { std::memset(&r, 0, sizeof(r)); r.candidate = -1; }
   auto fill_host = [&](int k, Record* dst) {
@@ -309,7 +241,6 @@ int run_dealt_batch(dgs_group* g, int n, const std::vector<std::vector<int>>& id
   };
   bool ok = have_buffers;
   for (int k = 0; k < G && ok; k++) {
-    if (dev_ok[k]) continue;
     char* hs = static_cast<char*>(g->h_stage[k]);
     std::vector<Record> mine(per);
     for (auto& r : mine) { std::memset(&r, 0, sizeof(r)); r.candidate = -1; }
@@ -340,7 +271,7 @@ int run_dealt_batch(dgs_group* g, int n, const std::vector<std::vector<int>>& id
     }
     if (!ok) g->err = "dgs_group: RCCL all-gather failed, gathered on the host instead";
   } else if (ok) {
-    // no communicators (a device listed twice, or no RCCL): every member's device-written records come to the host directly
+    // no communicators (a device listed twice, or no RCCL): every member's records come back from its device buffer directly
     for (int k = 0; k < G && ok; k++)
       ok = hipSetDevice(g->devices[k]) == hipSuccess &&
            hipMemcpyAsync(g->h_stage[k], g->d_send[k], (size_t)per * kRecordBytes, hipMemcpyDeviceToHost, g->members[k]->stream) == hipSuccess;

@@ -57,13 +57,25 @@ __device__ __forceinline__ unsigned strict_neighbourhood(const float (&xt)[3], c
   const int c1 = (int)floorf(leaf_pow2 ? xt[1] * g.inv_leaf : xt[1] / g.leaf);
   const int c2 = (int)floorf(leaf_pow2 ? xt[2] * g.inv_leaf : xt[2] / g.leaf);
   unsigned mask = 0;
+  // interior cells (every neighbour inside the grid) need no per-neighbour bounds test: base pointer + fixed offsets
+  const bool interior = c0 > g.min_b[0] && c0 < g.max_b[0] && c1 > g.min_b[1] && c1 < g.max_b[1] && c2 > g.min_b[2] && c2 < g.max_b[2];
+  if (interior) {
+    const int* __restrict__ base = g.cell2vox + ((c0 - g.min_b[0]) + (c1 - g.min_b[1]) * g.mul1 + (c2 - g.min_b[2]) * g.mul2);
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
-    int dx, dy, dz;
-    neighbour_offset<SEARCH>(k, dx, dy, dz);
-    const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
-    const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
-    vids[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+    for (int k = 0; k < NB; k++) {
+      int dx, dy, dz;
+      neighbour_offset<SEARCH>(k, dx, dy, dz);
+      vids[k] = base[dx + dy * g.mul1 + dz * g.mul2];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      int dx, dy, dz;
+      neighbour_offset<SEARCH>(k, dx, dy, dz);
+      const int a0 = c0 + dx, a1 = c1 + dy, a2 = c2 + dz;
+      const bool inb = a0 >= g.min_b[0] && a0 <= g.max_b[0] && a1 >= g.min_b[1] && a1 <= g.max_b[1] && a2 >= g.min_b[2] && a2 <= g.max_b[2];
+      vids[k] = inb ? g.cell2vox[(a0 - g.min_b[0]) + (a1 - g.min_b[1]) * g.mul1 + (a2 - g.min_b[2]) * g.mul2] : -1;
+    }
   }
   if (SEARCH == DGS_NDT_KDTREE) {
     const float r2 = g.leaf * g.leaf;
@@ -156,14 +168,28 @@ __device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&
   acc[0] += (double)score_inc;
 }
 
-// the point's products with the float angle tables (computePointDerivatives)
+// the point's products with the float angle tables (computePointDerivatives).  As in the default order's kernel: rows 5..7 of the first
+// table and rows 4, 5, 9..14 of the second have an exact zero z entry (the term adds +-0: skipped), and nine of the fifteen second-table rows
+// are first-table rows again -- the same double expressions or their exact negations (a2 = -b, a3 = a, b2 = -e, b3 = d, c2 = -h, c3 = g,
+// f1 / f2 / f3 = the xy parts of d1 / a2 / a3), so the float products are the same bits or their negations (IEEE rounding is symmetric).
 template <bool NEED_H>
 __device__ __forceinline__ void strict_point_tables(const float4 x, const NdtPair& st, float (&xj)[8], float (&xh)[15]) {
+  const float jxy0 = st.jang[0][0] * x.x + st.jang[0][1] * x.y, jxy1 = st.jang[1][0] * x.x + st.jang[1][1] * x.y;
+  xj[0] = jxy0 + st.jang[0][2] * x.z;
+  xj[1] = jxy1 + st.jang[1][2] * x.z;
 #pragma unroll
-  for (int i = 0; i < 8; i++) xj[i] = st.jang[i][0] * x.x + st.jang[i][1] * x.y + st.jang[i][2] * x.z;
+  for (int i = 2; i < 5; i++) xj[i] = st.jang[i][0] * x.x + st.jang[i][1] * x.y + st.jang[i][2] * x.z;
+#pragma unroll
+  for (int i = 5; i < 8; i++) xj[i] = st.jang[i][0] * x.x + st.jang[i][1] * x.y;
   if (NEED_H) {
+    xh[0] = -xj[1]; xh[1] = xj[0]; xh[2] = -xj[4]; xh[3] = xj[3]; xh[4] = -xj[7]; xh[5] = xj[6];
+    const float hxy6 = st.hang[6][0] * x.x + st.hang[6][1] * x.y;
+    xh[6] = hxy6 + st.hang[6][2] * x.z;
 #pragma unroll
-    for (int i = 0; i < 15; i++) xh[i] = st.hang[i][0] * x.x + st.hang[i][1] * x.y + st.hang[i][2] * x.z;
+    for (int i = 7; i < 9; i++) xh[i] = st.hang[i][0] * x.x + st.hang[i][1] * x.y + st.hang[i][2] * x.z;
+#pragma unroll
+    for (int i = 9; i < 12; i++) xh[i] = st.hang[i][0] * x.x + st.hang[i][1] * x.y;
+    xh[12] = hxy6; xh[13] = -jxy1; xh[14] = jxy0;
   } else {
 #pragma unroll
     for (int i = 0; i < 15; i++) xh[i] = 0.f;

@@ -42,11 +42,17 @@ def timed(fn, reps, warm=2):
     return float(np.median(ts)), ts
 
 
-def ndt_pair(name, tgt, src, res, guess, reps, cpu, orc, threads):
+ORDER_NAME = {0: "fast order", 1: "upstream order (the timed mode)"}
+KERNEL = {0: "ndt_derivatives_kernel<DIRECT7, fused>", 1: "ndt_strict3_kernel<DIRECT7, fused>"}
+REC_BYTES = {0: 48, 1: 64}
+
+
+def ndt_pair(name, tgt, src, res, guess, reps, cpu, orc, threads, order=1):
     import torch
     from delta_graph_slam_amd import _lib as L
     from delta_graph_slam_amd.registration import Registration
-    reg = Registration("NDT_OMP", ndt_resolution=res)
+    name = name + ", " + ORDER_NAME[order]
+    reg = Registration("NDT_OMP", ndt_resolution=res, ndt_strict_order=order)
     dt_, ds_ = torch.from_numpy(tgt).cuda(), torch.from_numpy(src).cuda()
     t_set, _ = timed(lambda: reg.setInputTarget(dt_), reps)
     reg.setInputSource(ds_)
@@ -61,15 +67,15 @@ def ndt_pair(name, tgt, src, res, guess, reps, cpu, orc, threads):
     ms_s, n_s = reg.profile_get(L.K_NDT_SOLVE)
     reg.profile_enable(False)
     c = reg.counts()
-    bytes_eval = 16 * src.shape[0] + 48 * c["valid_voxels"] + 344
-    out = {"config": name, "points": int(src.shape[0]), "resolution": res, "gpu_set_target_ms": 1e3 * t_set, "gpu_align_ms": 1e3 * t_align,
+    bytes_eval = 16 * src.shape[0] + REC_BYTES[order] * c["valid_voxels"] + 344
+    out = {"config": name, "ndt_strict_order": order, "points": int(src.shape[0]), "resolution": res, "gpu_set_target_ms": 1e3 * t_set, "gpu_align_ms": 1e3 * t_align,
            "gpu_fitness_ms": 1e3 * t_fit, "iterations": reg.last_result.iterations, "evaluations": ev, "converged": bool(reg.hasConverged()),
            "gpu_ms_per_evaluation": 1e3 * t_align / max(ev, 1), "ndt_derivatives_us": 1e3 * ms / max(n, 1), "ndt_solve_us": 1e3 * ms_s / max(n_s, 1),
            "ndt_derivatives_GBps": bytes_eval * ev * reps / (ms * 1e-3) / 1e9 if ms > 0 else None, "valid_voxels": c["valid_voxels"],
            "gpu_registrations_per_s": 1.0 / t_align}
     # the per-kernel roofline case "in isolation" -- one pair, every launch is one evaluation of it
     ach = bytes_eval * n / (ms * 1e-3) / 1e9 if ms > 0 else None
-    out["roofline"] = {"bound": "hbm", "kernel": "ndt_derivatives_kernel<DIRECT7, fused> (one pair: derivatives + the optimiser step in the closing workgroup)",
+    out["roofline"] = {"bound": "hbm", "kernel": KERNEL[order] + " (one pair: derivatives + the optimiser step in the closing workgroup)",
                        "algorithmic_bytes_per_launch": bytes_eval, "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1), "achieved": ach, "peak": 8000.0,
                        "unit": "GB/s", "frac": ach / 8000.0 if ach else None, "traffic": None,
                        "points_per_s": src.shape[0] * n / (ms * 1e-3) if ms > 0 else None}
@@ -146,6 +152,78 @@ def gicp_pair(name, method, tgt, src, guess, reps, cpu, orc, threads, **kw):
     return out
 
 
+def pmc_traffic(extra_args, kernel_substring):
+    """HBM bytes per launch of one kernel from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in separate
+    rocprofv3 --pmc passes (kernel trace only), KiB units, the read side doubled on gfx950 (an upper bound for gathers)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None or any(k.startswith(("ROCP_", "ROCPROF", "HSA_TOOLS_LIB")) for k in os.environ):
+        return None, {"error": "no rocprofv3, or already under a profiler"}
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dgs_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + extra_args
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+        except subprocess.TimeoutExpired:
+            return None, {"error": "rocprofv3 child timed out"}
+        tot, n = 0.0, 0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            per = {}
+            for r in csv.DictReader(open(f)):
+                if kernel_substring in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            tot += sum(per.values())
+            n += len(per)
+        shutil.rmtree(d, ignore_errors=True)
+        res[counter] = (tot * 1024.0 / n) if n else None
+        res[counter + "_launches"] = n
+    if res.get("FETCH_SIZE") is None or res.get("WRITE_SIZE") is None:
+        return None, res
+    return 2.0 * res["FETCH_SIZE"] + res["WRITE_SIZE"], res
+
+
+def cfg5_batched(order, reps, traffic=True, n_pairs=8):
+    """BASELINE configs[4] as the HBM stress it is named as: 8 pairs of 200,000-point indoor scans against one target, NDT
+    0.5 m, every derivative launch covers all pairs still iterating -- the roofline of the iteration kernel with the chip full."""
+    import torch
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd import synth
+    from delta_graph_slam_amd.registration import Registration
+    tgt, _, _ = synth.indoor_pair()
+    srcs = [synth.indoor_pair(seed_source=51 + 7 * k, t_gt=(0.10 - 0.02 * k, 0.05, 0.0), r_gt=(0.0, 0.0, 0.03 - 0.005 * k))[1] for k in range(n_pairs)]
+    reg = Registration("NDT_OMP", ndt_resolution=0.5, ndt_strict_order=order)
+    reg.setInputTarget(torch.from_numpy(tgt).cuda())
+    ds = [torch.from_numpy(x).cuda() for x in srcs]
+    t_batch, _ = timed(lambda: reg.align_batch(ds, None, compute_fitness=False), reps)
+    reg.profile_enable(True)
+    reg.profile_reset()
+    ev = 0
+    for _ in range(reps):
+        res = reg.align_batch(ds, None, compute_fitness=False)
+        ev += reg.counts()["evaluations"]
+    ms, n = reg.profile_get(L.K_NDT_DERIVATIVES)
+    reg.profile_enable(False)
+    c = reg.counts()
+    bytes_eval = 16 * srcs[0].shape[0] + REC_BYTES[order] * c["valid_voxels"] + 344
+    ach = bytes_eval * ev / (ms * 1e-3) / 1e9 if ms > 0 else None
+    out = {"config": "cfg5_batched: %d pairs of 200,000-point indoor scans per launch, NDT 0.5 m DIRECT7, %s" % (n_pairs, ORDER_NAME[order]), "ndt_strict_order": order,
+           "pairs": n_pairs, "points": int(srcs[0].shape[0]), "gpu_batch_ms": 1e3 * t_batch, "gpu_registrations_per_s": n_pairs / t_batch,
+           "evaluations_per_batch": ev / reps, "converged": [bool(r["converged"]) for r in res], "valid_voxels": c["valid_voxels"],
+           "roofline": {"bound": "hbm", "kernel": KERNEL[order], "bytes_per_evaluation": bytes_eval, "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1),
+                        "algorithmic_bytes_per_launch": bytes_eval * ev / max(n, 1), "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0 if ach else None,
+                        "traffic": None, "points_per_s": srcs[0].shape[0] * ev / (ms * 1e-3) if ms > 0 else None}}
+    if traffic:
+        t, detail = pmc_traffic(["--only-cfg5-batched", "--orders", str(order), "--reps", "4", "--no-cpu"], "ndt_strict3_kernel" if order == 1 else "ndt_derivatives_kernel")
+        out["roofline"]["traffic"] = t
+        out["roofline"]["traffic_detail"] = detail
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=100)
@@ -153,7 +231,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--only-ndt", action="store_true", help="the three single-pair NDT rows only (launch-shape sweeps: DGS_NDT_PPT / DGS_NDT_CAP / DGS_NDT_BLOCKS)")
+    ap.add_argument("--orders", type=int, nargs="*", default=[1, 0], help="NDT evaluation orders of the NDT rows (dgs_params.ndt_strict_order)")
+    ap.add_argument("--only-cfg5-batched", action="store_true", help="the cfg5_batched row only (the child runs of its PMC traffic passes)")
+    ap.add_argument("--no-traffic", action="store_true")
     args = ap.parse_args()
+    if args.only_cfg5_batched:
+        for order in args.orders:
+            print(json.dumps(cfg5_batched(order, max(2, args.reps // 2), traffic=False)), flush=True)
+        return
     import torch
     from delta_graph_slam_amd import synth
     from delta_graph_slam_amd.odometry import ScanMatchingOdometry
@@ -163,22 +248,28 @@ def main():
     th = min(args.cpu_threads, orc.max_threads())
 
     tgt, src, Tgt = synth.planar_pair()
-    print(json.dumps(ndt_pair("cfg1 planar 16k, NDT 1.0 m, identity guess", tgt, src, 1.0, None, args.reps, cpu, orc, th)), flush=True)
+    for order in args.orders:
+        print(json.dumps(ndt_pair("cfg1 planar 16k, NDT 1.0 m, identity guess", tgt, src, 1.0, None, args.reps, cpu, orc, th, order=order)), flush=True)
 
     tgt, src, Tgt = synth.kitti_pair()
-    print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, identity guess", tgt, src, 1.0, None, args.reps, cpu, orc, th)), flush=True)
+    for order in args.orders:
+        print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, identity guess", tgt, src, 1.0, None, args.reps, cpu, orc, th, order=order)), flush=True)
     g = Tgt.copy()
     g[0, 3] -= 0.25
     g[1, 3] += 0.10
-    print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, odometry-like guess (0.27 m off)", tgt, src, 1.0, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
+    for order in args.orders:
+        print(json.dumps(ndt_pair("cfg2 HDL-64E 65,536 pair, NDT 1.0 m, odometry-like guess (0.27 m off)", tgt, src, 1.0, g.astype(np.float32), args.reps, cpu, orc, th, order=order)), flush=True)
 
     if not args.only_ndt:
       print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_GICP dmax 2.5, odometry-like guess", "FAST_GICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th)), flush=True)
       print(json.dumps(gicp_pair("cfg2 HDL-64E 65,536 pair, FAST_VGICP res 1.0 DIRECT1, odometry-like guess", "FAST_VGICP", tgt, src, g.astype(np.float32), args.reps, cpu, orc, th, vgicp_resolution=1.0)), flush=True)
 
     tgt, src, Tgt = synth.indoor_pair()
-    print(json.dumps(ndt_pair("cfg5 indoor 200k pair, NDT 0.5 m, identity guess", tgt, src, 0.5, None, max(3, args.reps // 2), cpu, orc, th)), flush=True)
+    for order in args.orders:
+        print(json.dumps(ndt_pair("cfg5 indoor 200k pair, NDT 0.5 m, identity guess", tgt, src, 0.5, None, max(3, args.reps // 2), cpu, orc, th, order=order)), flush=True)
 
+    for order in args.orders:   # cfg5 as the stress row BASELINE names: 8 pairs of 200,000 points per launch, the chip full
+        print(json.dumps(cfg5_batched(order, max(3, args.reps // 2), traffic=not args.no_traffic)), flush=True)
     if args.only_ndt:
         return
     # ---- cfg3: VLP-16 stream through the odometry driver, FAST_GICP with the launch-file values

@@ -257,3 +257,36 @@ def test_cfg4_at_its_full_candidate_count_256_candidates_over_8_members(oracle_l
     assert np.array_equal(res2[last]["T"], res2[b_ref]["T"]) and res2[last]["fitness"] == res2[b_ref]["fitness"]
     assert g.best_index == last
     g.close()
+
+
+def test_two_distinct_devices_rccl_gather_peer_clone_and_owner_dealing(oracle_lib):
+    """The G > 1 paths that one-GPU boxes cannot reach (skipped there): ncclAllGather over two communicators, a candidate keyframe promoted
+    to a target on the OTHER device (hipMemcpyPeerAsync in cloud_clone_to), and dealing by owner when G does not divide the candidate
+    count -- against dgs_align_batch on one device, bit for bit.  Runs on the first multi-GPU node this suite meets."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from delta_graph_slam_amd.registration import Registration
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=7, n_points=16384, seed=40, distinct_scans=5)
+    one = Registration("NDT_OMP", device=0, ndt_resolution=1.0, ndt_strict_order=1)
+    one.setInputTarget(tgt)
+    ref = one.align_batch(sources, guesses)
+    g = RegistrationGroup("NDT_OMP", devices=[0, 1], ndt_resolution=1.0, ndt_strict_order=1)
+    assert g.uses_rccl and g.rccl_ranks == 2
+    kf = [g.make_cloud(sources[k], owner=k) for k in range(5)]       # owners 0,1,0,1,0: candidates 5, 6 re-use keyframes 0, 1
+    g.setInputTarget(g.make_cloud(tgt))
+    res = g.align_batch([kf[c % 5] for c in range(7)], guesses)
+    assert g.last_gather_used_rccl
+    for c in range(7):
+        assert np.array_equal(res[c]["T"], ref[c]["T"]) and res[c]["converged"] == ref[c]["converged"], c
+        assert abs(res[c]["fitness"] - ref[c]["fitness"]) <= 1e-12 * ref[c]["fitness"], c
+    # a candidate keyframe owned by device 1 becomes the target: every member needs it (peer copy), results equal the single-device run
+    one.setInputTarget(sources[1])
+    ref2 = one.align_batch([sources[0], sources[2]], None)
+    g.setInputTarget(kf[1])
+    res2 = g.align_batch([kf[0], kf[2]], None)
+    for c in range(2):
+        assert np.array_equal(res2[c]["T"], ref2[c]["T"]), c
+    assert kf[1].copies == 2
+    g.close()
+    one.close()
