@@ -1785,6 +1785,7 @@ static void launch_strict_rows(dgs_handle* h, const NdtLaunch& L, const dim3 gri
 // accumulators, 47 ms per step.)
 static int strict_kernel_version(const dgs_handle* h) { return h->strict_kernel == 2 ? 2 : 3; }
 
+
 // item-compacted kernel, fused launches: the Newton steps of the closings go to ndt_strict_solve_kernel on the third stream
 static bool strict_solve_beside(const dgs_handle* h) {
   return strict_kernel_version(h) == 3 && h->n_occupied_bound < (1 << 25) && h->ndt_fused && h->solve_min_active > 0 && h->hd_stream != nullptr &&

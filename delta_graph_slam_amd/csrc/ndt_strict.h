@@ -349,8 +349,13 @@ __device__ __forceinline__ void strict_block_row(const double (&acc)[kStrictAccu
 #else
 #define STRICT_STAMP(k)
 #endif
+#ifdef DGS_STRICT_CLOSE_NOINLINE
+#define DGS_CLOSE_INLINE __noinline__
+#else
+#define DGS_CLOSE_INLINE __forceinline__
+#endif
 template <bool HD, bool ONE_KERNEL = false>
-__device__ __forceinline__ void ndt_close_strict(NdtPair* st, const double* rows_of_pair, const int blocks_per_pair, const NdtConsts& c, int* done_flag, const int launch,
+__device__ DGS_CLOSE_INLINE void ndt_close_strict(NdtPair* st, const double* rows_of_pair, const int blocks_per_pair, const NdtConsts& c, int* done_flag, const int launch,
                                                  const int hd_lag = 1, const bool defer_solve = false) {
   STRICT_STAMP(0)
   __shared__ NdtSolver s_lds;
@@ -505,7 +510,10 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
 template <int SEARCH, bool WITH_HD>
 struct StrictTile {
   static constexpr int NB = Offsets<SEARCH>::N;
-  static constexpr int PTS = (NB <= 7 && WITH_HD) ? 128 : 64;   // points per wave and tile (float kinds)
+#ifndef DGS_STRICT_PTS_FLOAT_ONLY
+#define DGS_STRICT_PTS_FLOAT_ONLY 64
+#endif
+  static constexpr int PTS = (NB <= 7) ? (WITH_HD ? 128 : DGS_STRICT_PTS_FLOAT_ONLY) : 64;   // points per wave and tile (float kinds)
   static constexpr int PTS_HD = 64;                  // double pass: 23 doubles + 3 floats per point
   static constexpr int kFields = 26;                 // xt[3], xj[8], xh[15]
   static constexpr int kTableBytes = (!WITH_HD || kFields * PTS * 4 > (23 * 8 + 3 * 4) * PTS_HD) ? kFields * PTS * 4 : (23 * 8 + 3 * 4) * PTS_HD;
@@ -545,7 +553,9 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
   double* td = reinterpret_cast<double*>(s_tab[wave]);          // double pass: [23][PTS_HD] doubles, then [3][PTS_HD] floats
   float* tdx = reinterpret_cast<float*>(s_tab[wave] + 23 * 8 * TL::PTS_HD);
   unsigned* queue = s_queue[wave];
-  const int pts = (WITH_HD && kind == 2) ? TL::PTS_HD : TL::PTS;           // wave-uniform
+  // wave-uniform.  (Keeping it opaque to the optimiser -- asm volatile("" : "+s"(pts)) -- takes the kernel from 256 VGPRs + 4 spilled to 239
+  // without spills, and the step from 6.25 to 6.6 ms: the loops specialised per tile size are worth more than the registers.)
+  const int pts = (WITH_HD && kind == 2) ? TL::PTS_HD : TL::PTS;
   const int subs = pts / 64;
   const int stride = blocks_per_pair * kBlock;
   // the wave's points: i = first + lane + sub * stride, tiles of `subs` strides
