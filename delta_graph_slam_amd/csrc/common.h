@@ -111,6 +111,12 @@ struct NdtPair {
   //             (r + 2) is read as "not this round" before and after the store alike.
   // The item-compacted kernel (one launch per round) uses serve[0] alone.
   int serve[4];
+  // Speculated Newton steps of the upstream order (ndt_strict.h "deferred exact solve"): the closing publishes the next evaluation from the
+  // 2-us Gauss-Jordan direction (spec_pending = 1); one wave of the pair's first workgroup in the NEXT launch runs the exact Jacobi-SVD step
+  // beside the derivative work and leaves the exact optimiser state here with spec_result = 1 (the exact step yields the very float header
+  // that was published: adopt the state) or 2 (it does not, or the exact step ends the registration: discard the evaluation, decide exactly).
+  NdtSolver spec_s;
+  int spec_pending, spec_result, pad_spec[2];
 };
 
 // ---- per-pair GICP optimiser state (fast_gicp::LsqRegistration) -------------------------------
@@ -189,7 +195,9 @@ struct NdtInit {  // host -> device per pair, per align
 // Returns false when this workgroup has nothing to do.  gridDim.x must be >= the number of pairs.
 #ifdef __HIPCC__
 template <class Pred>
-__device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, Pred pred, int& pair, int& slice, int& blocks_per_pair, int* n_active_out = nullptr) {
+__device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, Pred pred, int& pair, int& slice, int& blocks_per_pair, int* n_active_out = nullptr,
+                                      const int block_id_in = -1, const int grid_in = -1) {
+  const int block_id = block_id_in >= 0 ? block_id_in : (int)blockIdx.x, grid = grid_in >= 0 ? grid_in : (int)gridDim.x;   // a kernel may keep some workgroups for other work
   const int lane_id = threadIdx.x & 63;
   int n_active = 0;
   for (int c0 = 0; c0 < n_pairs; c0 += 64) {
@@ -199,9 +207,9 @@ __device__ inline bool deal_workgroup(const int n_pairs, const int cap_blocks, P
   }
   if (n_active_out) *n_active_out = n_active;
   if (n_active == 0) return false;
-  blocks_per_pair = max(1, min((int)gridDim.x / n_active, cap_blocks));
-  const int rank = blockIdx.x / blocks_per_pair;
-  slice = blockIdx.x % blocks_per_pair;
+  blocks_per_pair = max(1, min(grid / n_active, cap_blocks));
+  const int rank = block_id / blocks_per_pair;
+  slice = block_id % blocks_per_pair;
   if (rank >= n_active) return false;
   int found = -1, seen = 0;
   for (int c0 = 0; c0 < n_pairs && found < 0; c0 += 64) {

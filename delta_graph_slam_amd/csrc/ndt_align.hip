@@ -851,12 +851,18 @@ __device__ inline double dot6(const double* a, const double* b) {
 // STRICT: the upstream evaluation orders -- JacobiSVD(H).solve(-g) in the CPU checker's sequence of operations (Eigen's two-sided
 // Jacobi across the wave, or rounds 2-3's one-sided Jacobi: dgs_params.ndt_newton_solver); otherwise the default order's Gauss-Jordan
 // step.  A template argument, not a run-time test, so that the default order's fused kernel carries none of the SVD code.
+// fast_solver (STRICT only): the direction from the Gauss-Jordan elimination instead -- a SPECULATED step (ndt_strict.h): the exact one follows
+// beside the next launch and the closing behind it verifies; *fast_ok tells whether the elimination was well conditioned.
 template <bool STRICT, bool SVD_REGS, bool COH = false>
-__device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer) {
+__device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer, const bool fast_solver = false, bool* fast_ok = nullptr) {
   double neg_g[6], delta[6], rc;
 #pragma unroll
   for (int k = 0; k < 6; k++) neg_g[k] = -s.grad[k];
-  if (STRICT) {
+  if (STRICT && fast_solver) {
+    gj_solve6_columns(s.hess, s.grad, delta, &rc);
+    *fast_ok = rc > 1e-10;
+    if (!*fast_ok) return false;
+  } else if (STRICT) {
     if (c.newton_solver) jsvd_solve6_wave(s.hess, neg_g, delta);
     else if (SVD_REGS) svd_solve6_regs_dev(s.hess, neg_g, delta, 1e-17, 60);
     else svd_solve6_dev(s.hess, neg_g, delta, 1e-17, 60);
@@ -954,8 +960,11 @@ __device__ __forceinline__ void queue_trial(NdtPair* st, NdtPair* hdr, NdtSolver
 // SVD_REGS: the stand-alone solve launch of the validation modes keeps the SVD workspace in registers (solve6.h)
 // defer_solve (upstream order, ndt_strict.h): stop in front of the next iteration's Newton step (phase PH_SOLVE_PENDING); a later call
 // with that phase -- from ndt_strict_solve_kernel -- continues there.
+// speculate (upstream order, fused item-compacted kernel): take the next iteration's Newton step from the fast solver and tell the caller
+// (*speculated) -- see NdtPair::spec_s.
 template <bool SVD_REGS = false, bool COH = false, bool STRICT = false>
-__device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer, bool defer_solve = false) {
+__device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver& s, const NdtConsts& c, bool writer, bool defer_solve = false, bool speculate = false,
+                                            bool* speculated = nullptr) {
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
   const bool resume = STRICT && s.phase == PH_SOLVE_PENDING;
   if (!resume) s.evaluations++;
@@ -1014,6 +1023,18 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
     if (STRICT && defer_solve) {   // the Newton step goes to the solve kernel
       s.phase = PH_SOLVE_PENDING;
       return;
+    }
+    if (STRICT && speculate) {
+      bool ok = false;
+      const int ph0 = s.phase, cv0 = s.converged;
+      if (begin_iteration<STRICT, SVD_REGS, COH>(st, hdr, s, c, writer, true, &ok)) {   // evaluation queued from the speculated direction
+        *speculated = true;
+        return;
+      }
+      s.phase = ph0;
+      s.converged = cv0;
+      // ill-conditioned, or the fast step ends / skips the iteration: nothing was published that the exact step below does not overwrite
+      // (its inputs -- p, score, gradient, Hessian -- are untouched)
     }
     if (begin_iteration<STRICT, SVD_REGS, COH>(st, hdr, s, c, writer)) return;  // evaluation queued
     if (s.phase == PH_DONE) return;
@@ -1557,6 +1578,8 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   st->serve[1] = -1;
   st->serve[2] = -1;
   st->serve[3] = 0;
+  st->spec_pending = 0;
+  st->spec_result = 0;
   if (queue) {   // queue kernel: the record slot of round 0
     const int* from = reinterpret_cast<const int*>(st);
     int* to = reinterpret_cast<int*>(queue_slot(ring, ring_rounds, i, 0));
@@ -1796,14 +1819,16 @@ template <int SEARCH>
 static void launch_strict_sums(dgs_handle* h, const NdtLaunch& L, const dim3 grid, const int leaf_pow2, const int launch, const bool hd) {
   if (strict_kernel_version(h) == 3 && h->n_occupied_bound < (1 << 25)) {
     if (hd && launch >= 0) return;   // one kernel serves every kind (launch < 0: the test hook asks for the kind it has set up)
+    const int spec = (launch >= 0 && h->ndt_speculate && h->consts.newton_solver && !strict_solve_beside(h)) ? 1 : 0;
+    const dim3 grid_s(grid.x + (spec ? L.n_pairs : 0));   // + one solver workgroup per pair, in front (ndt_strict.h)
     if (launch >= 0)
-      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
+      hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true, true>), grid_s, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
                          h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
-                         h->done_flags, launch, strict_solve_beside(h) ? h->solve_min_active : 0);
+                         h->done_flags, launch, strict_solve_beside(h) ? h->solve_min_active : 0, spec);
     else
       hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, false, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
                          h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
-                         h->done_counter.ptr, launch, 0);
+                         h->done_counter.ptr, launch, 0, 0);
     return;
   }
   const bool beside = hd && launch >= 0 && h->hd_overlap && h->hd_stream;   // the computeHessian launch on its own stream, beside the next round's first launch

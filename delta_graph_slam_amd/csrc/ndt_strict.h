@@ -356,14 +356,19 @@ __device__ __forceinline__ void strict_block_row(const double (&acc)[kStrictAccu
 #endif
 template <bool HD, bool ONE_KERNEL = false>
 __device__ DGS_CLOSE_INLINE void ndt_close_strict(NdtPair* st, const double* rows_of_pair, const int blocks_per_pair, const NdtConsts& c, int* done_flag, const int launch,
-                                                 const int hd_lag = 1, const bool defer_solve = false) {
+                                                 const int hd_lag = 1, const bool defer_solve = false, const bool speculate = false) {
   STRICT_STAMP(0)
   __shared__ NdtSolver s_lds;
   NdtSolver& s = s_lds;
   static_assert(sizeof(NdtSolver) % 8 == 0 && sizeof(NdtSolver) / 8 <= kBlock, "state words");
   constexpr int kWords = (int)(sizeof(NdtSolver) / 8);
   double word = 0.0;
-  if (threadIdx.x < kWords) word = reinterpret_cast<const double*>(&st->s)[threadIdx.x];
+  // a speculated step behind this evaluation (NdtPair::spec_s): the exact state and its verdict were left by a wave of THIS launch -> coherent loads
+  const int spec_pending = st->spec_pending;
+  const int spec_result = spec_pending ? __hip_atomic_load(&st->spec_result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  if (threadIdx.x < kWords)
+    word = (spec_pending && spec_result != 0) ? __hip_atomic_load(reinterpret_cast<const double*>(&st->spec_s) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : reinterpret_cast<const double*>(&st->s)[threadIdx.x];
   const int kind = st->need_hessian;
   __shared__ double tot[kStrictPad];
   constexpr int G = kBlock / kStrictPad;   // 5 groups of 48 columns; threads 240.. idle
@@ -396,7 +401,11 @@ __device__ DGS_CLOSE_INLINE void ndt_close_strict(NdtPair* st, const double* row
   STRICT_STAMP(1)
   if (threadIdx.x >= kWave) return;
   const bool writer = threadIdx.x == 0;
-  {
+  // spec_result 1: the state just loaded IS the exact one (its step yields the published header): consume the evaluation as ever.
+  // spec_result 2 (or a missing verdict): the evaluation was made from a header the exact step does not yield, or the exact step ends the
+  // registration: drop its sums and take the step exactly, here (the state loaded is the exact wave's copy; its inputs are the iteration's).
+  const bool redo = spec_pending && spec_result != 1;
+  if (!redo) {
     const int t = threadIdx.x;
     if (t < 36) {
       if (kind) s.hess[t] = tot[7 + t];   // upstream's full 6 x 6 (not exactly symmetric)
@@ -405,17 +414,22 @@ __device__ DGS_CLOSE_INLINE void ndt_close_strict(NdtPair* st, const double* row
     } else if (t == 42) {
       if (kind != 2) s.score = tot[0];    // computeHessian alone (kind 2) leaves score and gradient as the last trial left them
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+  } else if (threadIdx.x == 0) {
+    s.phase = PH_SOLVE_PENDING;           // ndt_advance resumes in front of the Newton step, without counting an evaluation
   }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
   STRICT_STAMP(2)
-  ndt_advance<false, false, true>(st, st, s, c, writer, defer_solve);
+  bool speculated = false;
+  ndt_advance<false, false, true>(st, st, s, c, writer, defer_solve, speculate, &speculated);
   STRICT_STAMP(3)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
   for (int w = threadIdx.x; w < kWords; w += kWave) reinterpret_cast<double*>(&st->s)[w] = reinterpret_cast<const double*>(&s_lds)[w];
   STRICT_STAMP(4)
   if (writer) {
+    st->spec_pending = speculated ? 1 : 0;
+    if (speculated) st->spec_result = 0;
     if (s.phase == PH_DONE) {
       st->active = 0;
       if (launch >= 0) {
@@ -525,15 +539,30 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
                                                                const VoxelGrid g, const VoxelStrictRec* __restrict__ vs, const double* __restrict__ vtab,
                                                                const double gauss_d1, const double gauss_d2, const int leaf_pow2, double* __restrict__ partials,
                                                                const int n_pairs, const int cap_blocks, int* __restrict__ pair_blocks, const NdtConsts consts,
-                                                               int* __restrict__ done_flags, const int launch, const int solve_min_active) {
+                                                               int* __restrict__ done_flags, const int launch, const int solve_min_active, const int speculate) {
   using TL = StrictTile<SEARCH, WITH_HD>;
   constexpr int NB = TL::NB;
   int pair, slice, blocks_per_pair;
   int n_active = 0;
-  if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) {
-        return FUSED ? (launch <= pairs[pi].serve[0] || launch == pairs[pi].serve[2]) : (pairs[pi].active != 0 && (WITH_HD || pairs[pi].need_hessian != 2));
-      }, pair, slice, blocks_per_pair, &n_active)) return;
-  if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
+  // speculate: the first n_pairs workgroups of the grid are SOLVER workgroups, one per pair -- dispatched first, so that the exact Newton step
+  // of a pair whose evaluation was published from the speculated direction (NdtPair::spec_s) runs beside the derivative work from the very
+  // start of the launch; the remaining workgroups are dealt to the pairs of the round as ever.  A solver workgroup takes a ticket like a slice.
+  const int n_solvers = (FUSED && speculate) ? n_pairs : 0;
+  const bool solver = (int)blockIdx.x < n_solvers;
+  auto in_round = [&](int pi) {
+    return FUSED ? (launch <= pairs[pi].serve[0] || launch == pairs[pi].serve[2]) : (pairs[pi].active != 0 && (WITH_HD || pairs[pi].need_hessian != 2));
+  };
+  if (solver) {
+    pair = (int)blockIdx.x;
+    if (!in_round(pair) || !pairs[pair].spec_pending) return;
+    slice = -1;
+    const int lane_id = threadIdx.x & 63;
+    for (int c0 = 0; c0 < n_pairs; c0 += 64) n_active += __popcll(__ballot(c0 + lane_id < n_pairs && in_round(c0 + lane_id)));
+    blocks_per_pair = max(1, min(((int)gridDim.x - n_solvers) / n_active, cap_blocks));   // as deal_workgroup derives it
+  } else {
+    if (!deal_workgroup(n_pairs, cap_blocks, in_round, pair, slice, blocks_per_pair, &n_active, (int)blockIdx.x - n_solvers, (int)gridDim.x - n_solvers)) return;
+    if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
+  }
   const NdtPair& st = pairs[pair];
   const float4* __restrict__ src = src_ptrs[pair];
   const int n = src_sizes[pair];
@@ -556,11 +585,34 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
   // wave-uniform.  (Keeping it opaque to the optimiser -- asm volatile("" : "+s"(pts)) -- takes the kernel from 256 VGPRs + 4 spilled to 239
   // without spills, and the step from 6.25 to 6.6 ms: the loops specialised per tile size are worth more than the registers.)
   const int pts = (WITH_HD && kind == 2) ? TL::PTS_HD : TL::PTS;
+  if (solver && wave == 0) {
+    // ---- the deferred exact Newton step (NdtPair::spec_s).  The evaluation this launch computes for the pair was published from the
+    // Gauss-Jordan direction; this wave takes the step the way the reference does -- JacobiSVD(H).solve(-g), the same begin_iteration code,
+    // every lane alike -- on a copy of the optimiser state, writing the header it yields into LDS, and compares: 82 words, bit for bit.
+    __shared__ NdtSolver s_x;
+    NdtPair* scratch = reinterpret_cast<NdtPair*>(s_tab[0]);   // this wave's table region: free until its first tile
+    constexpr int kWords = (int)(sizeof(NdtSolver) / 8);
+    for (int w = lane; w < kWords; w += kWave) reinterpret_cast<double*>(&s_x)[w] = reinterpret_cast<const double*>(&st.s)[w];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const bool queued = begin_iteration<true, false, false>(scratch, scratch, s_x, consts, lane == 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    bool same = queued;
+    const int* pub = reinterpret_cast<const int*>(&st);            // T[12], jang[8][3], hang[15][3], need_hessian: the first 82 words
+    const int* mine = reinterpret_cast<const int*>(scratch);
+    for (int w = lane; w < 82; w += kWave) same = same && (pub[w] == mine[w]);
+    same = __all(same) != 0;
+    for (int w = lane; w < kWords; w += kWave)
+      __hip_atomic_store(reinterpret_cast<double*>(&pairs[pair].spec_s) + w, reinterpret_cast<const double*>(&s_x)[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&pairs[pair].spec_result, same ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_wave_barrier();
+  }
   const int subs = pts / 64;
   const int stride = blocks_per_pair * kBlock;
   // the wave's points: i = first + lane + sub * stride, tiles of `subs` strides
 #pragma unroll 1
-  for (int first = slice * kBlock + wave * 64; first < n; first += subs * stride) {
+  for (int first = solver ? n : slice * kBlock + wave * 64; first < n; first += subs * stride) {
     int qn = 0;
 #pragma unroll 1
     for (int sub = 0; sub < subs; sub++) {
@@ -649,12 +701,14 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
     __builtin_amdgcn_wave_barrier();   // the next tile overwrites the tables and the queue (LDS operations of one wave stay in order)
   }
   static_assert(TL::kTableBytes >= kStrictRowScratch * 8, "the wave's table region doubles as its reduction scratch");
-  strict_block_row<FUSED, false>(acc, kind ? kStrictAccum : 7, partials + ((size_t)pair * cap_blocks + slice) * kStrictPad, td);
+  if (!solver) strict_block_row<FUSED, false>(acc, kind ? kStrictAccum : 7, partials + ((size_t)pair * cap_blocks + slice) * kStrictPad, td);
   if (!FUSED) return;
   __shared__ int s_last;
-  if (threadIdx.x < kStrictPad) handoff_drain_stores();
+  if (threadIdx.x < kStrictPad) handoff_drain_stores();   // (solver: the exact state's write-through stores)
   __syncthreads();
-  if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, blocks_per_pair) ? 1 : 0;
+  // tickets of the pair in this launch: its slices, and its solver workgroup when a speculated step is pending (read before anybody can close)
+  const int n_tickets = blocks_per_pair + ((speculate && st.spec_pending) ? 1 : 0);
+  if (threadIdx.x == 0) s_last = handoff_take_ticket(&pairs[pair].ticket, n_tickets) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
 #ifdef DGS_CLOSE_STAMPS
@@ -662,7 +716,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
 #endif
   // with enough other pairs to keep the chip busy the Newton step (a ~40 us dependent chain on one wave) leaves the launch: solve_min_active > 0
   ndt_close_strict<false, WITH_HD>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch, 1,
-                                   solve_min_active > 0 && n_active >= solve_min_active);
+                                   solve_min_active > 0 && n_active >= solve_min_active, speculate != 0);
 }
 
 // The Newton steps that the closings of round `launch` left behind (NdtPair::serve[1] == launch, phase PH_SOLVE_PENDING): one wave per pair,
