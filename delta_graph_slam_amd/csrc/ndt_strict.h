@@ -135,6 +135,49 @@ __device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&
   for (int c = 0; c < 3; c++) g6[3 + c] = q0 * cPG[0][c] + q1 * cPG[1][c] + q2 * cPG[2][c];
 #pragma unroll
   for (int c = 0; c < 6; c++) acc[1 + c] += (double)(e * g6[c]);
+#ifdef DGS_STRICT_PACKED_H   // A/B build (-DDGS_STRICT_PACKED_H): measured on the bench step 5.25-5.28 ms against 5.22 ms for the scalar form below -- the block shrinks from
+                            // 383 to 320 instructions (54 v_pk_mul_f32, 33 v_pk_add_f32, 19 moves), bit-identical results, no gain: at 2 waves per SIMD the
+                            // item loop waits on the voxel record's L2 latency and the LDS reads, not on issue slots
+  if (NEED_H) {
+    // The same 36 Hessian increments on PACKED FP32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE single operations per instruction, each component
+    // rounded on its own -- the same values as the scalar form below, operation for operation): entries (i, 2m) and (i, 2m + 1) of a row share
+    // an instruction.  Column pairs of J^T (C J_i): (cj0, cj1) | (cj2, pcp3) | (pcp4, pcp5), the last one from the point-gradient pairs
+    // (pg4[k], pg5[k]).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    float xch[6];
+    xch[0] = qC[1] * xh[0] + qC[2] * xh[1];
+    xch[1] = qC[1] * xh[2] + qC[2] * xh[3];
+    xch[2] = qC[1] * xh[4] + qC[2] * xh[5];
+    xch[3] = qC[0] * xh[6] + qC[1] * xh[7] + qC[2] * xh[8];
+    xch[4] = qC[0] * xh[9] + qC[1] * xh[10] + qC[2] * xh[11];
+    xch[5] = qC[0] * xh[12] + qC[1] * xh[13] + qC[2] * xh[14];
+    const v2f G01 = {g6[0], g6[1]}, G23 = {g6[2], g6[3]}, G45 = {g6[4], g6[5]};
+    const v2f PG45_0 = {pg4[0], pg5[0]}, PG45_1 = {pg4[1], pg5[1]}, PG45_2 = {pg4[2], pg5[2]};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const float ng = -gd2 * g6[i];
+      const float cj0 = (i < 3) ? C[0][i < 3 ? i : 0] : cPG[0][i < 3 ? 0 : i - 3];
+      const float cj1 = (i < 3) ? C[1][i < 3 ? i : 0] : cPG[1][i < 3 ? 0 : i - 3];
+      const float cj2 = (i < 3) ? C[2][i < 3 ? i : 0] : cPG[2][i < 3 ? 0 : i - 3];
+      v2f T01 = ng * G01, T23 = ng * G23, T45 = ng * G45;
+      if (i >= 3) {
+        // (i, 3), (i, 4), (i, 5): the vectors of the point Hessian's rotational block: (3,3) (3,4) (3,5) | (3,4) (4,4) (4,5) | (3,5) (4,5) (5,5)
+        const int r = i - 3;
+        const float x3 = xch[r == 0 ? 0 : (r == 1 ? 1 : 2)], x4 = xch[r == 0 ? 1 : (r == 1 ? 3 : 4)], x5 = xch[r == 0 ? 2 : (r == 1 ? 4 : 5)];
+        T23.y = T23.y + x3;
+        const v2f X45 = {x4, x5};
+        T45 = T45 + X45;
+      }
+      const v2f P01 = {cj0, cj1};
+      const v2f P23 = {cj2, pg13 * cj1 + pg23 * cj2};
+      const v2f P45 = PG45_0 * cj0 + PG45_1 * cj1 + PG45_2 * cj2;
+      const v2f V01 = e * (T01 + P01), V23 = e * (T23 + P23), V45 = e * (T45 + P45);
+      acc[7 + i * 6 + 0] += (double)V01.x; acc[7 + i * 6 + 1] += (double)V01.y;
+      acc[7 + i * 6 + 2] += (double)V23.x; acc[7 + i * 6 + 3] += (double)V23.y;
+      acc[7 + i * 6 + 4] += (double)V45.x; acc[7 + i * 6 + 5] += (double)V45.y;
+    }
+  }
+#else
   if (NEED_H) {
     // x^T C H for the six distinct vectors: a = (0, xh0, xh1) b = (0, xh2, xh3) c = (0, xh4, xh5) d = xh6..8 e = xh9..11 f = xh12..14
     float xch[6];
@@ -165,6 +208,7 @@ __device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&
       }
     }
   }
+#endif
   acc[0] += (double)score_inc;
 }
 
