@@ -57,7 +57,7 @@ SYMBOLS = [
     "dgs_ndt_get_trajectory", "dgs_gicp_get_covariances", "dgs_gicp_linearize", "dgs_vgicp_get_voxels",
     "dgs_group_create", "dgs_group_destroy", "dgs_group_last_error", "dgs_group_size", "dgs_group_uses_rccl", "dgs_group_rccl_ranks", "dgs_group_last_gather_used_rccl",
     "dgs_group_member", "dgs_group_set_input_target", "dgs_group_align_batch",
-    "dgs_group_cloud_create", "dgs_group_cloud_destroy", "dgs_group_cloud_size", "dgs_group_cloud_copies", "dgs_group_set_input_target_cloud",
+    "dgs_group_cloud_create", "dgs_group_cloud_destroy", "dgs_group_cloud_size", "dgs_group_cloud_copies", "dgs_group_cloud_trim", "dgs_group_set_input_target_cloud",
     "dgs_group_align_batch_clouds",
 ]
 
@@ -138,6 +138,7 @@ def load(path=None):
     lib.dgs_group_cloud_size.argtypes = [C.c_void_p]
     lib.dgs_group_cloud_size.restype = C.c_int64
     lib.dgs_group_cloud_copies.argtypes = [C.c_void_p]
+    lib.dgs_group_cloud_trim.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.dgs_group_set_input_target_cloud.argtypes = [C.c_void_p, C.c_void_p]
     lib.dgs_group_align_batch_clouds.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, P(Result), P(C.c_int32),
                                                  P(C.c_double)]

@@ -266,7 +266,7 @@ int dgs_params_init(dgs_params* p, int32_t method) {
   p->ndt_line_search = DGS_NDT_LS_MORE_THUENTE;
   p->ndt_mt_max_step_iterations = 10;
   p->ndt_fix_hessian_d1 = 0;
-  p->ndt_strict_order = DGS_NDT_ORDER_FAST;
+  p->ndt_strict_order = DGS_NDT_ORDER_UPSTREAM;   // the order that reproduces a CPU run of upstream; FAST is the caller's choice
   p->ndt_newton_solver = 1;
   p->ndt_hessian_recompute_double = 1;
   p->ndt_guess_rotation_polar = 1;
@@ -369,6 +369,7 @@ void dgs_destroy(dgs_handle* h) {
   h->run_counts.release(); h->run_offsets.release(); h->dev_scalars.release(); h->vg_run_keys.release(); h->vg_scalars.release(); h->minmax_partial.release(); h->cub_temp.release();
   h->pairs.release(); h->inits.release(); h->partials.release(); h->done_counter.release(); h->ndt_queue.release(); h->ndt_ring.release(); h->pair_blocks.release(); h->src_ptrs.release(); h->src_sizes.release();
   h->nn_partials.release(); h->scratch_cloud.release(); h->strict_rows.release(); h->strict_totals.release(); h->tgt_grid.release(); h->aux_grid.release();
+  h->fc_in.release(); h->fc_out.release(); h->fc_cnt.release();
   h->aux_cloud1.release(); h->aux_cloud2.release(); h->aux_out.release(); h->aux_bvh.sorted.release(); h->aux_bvh.node_lo.release(); h->aux_bvh.node_hi.release();
   h->aux_bvh.keys.release(); h->aux_bvh.keys_alt.release(); h->aux_bvh.vals.release(); h->aux_bvh.vals_alt.release();
   h->corr.release(); h->corr_sq.release(); h->mahal.release(); h->gpairs.release();
@@ -874,37 +875,35 @@ int dgs_find_loop_candidates(dgs_handle* h, const double* accum_distance, const 
   if (set_device(h)) return DGS_ERR_HIP;
   *n_out = 0;
   if (n == 0) return DGS_OK;
-  // staging: [accum n | xy 2n] doubles, [indices cap] ints, one count
-  DevBuf<double> din;
-  DevBuf<int> dout;
-  DevBuf<long long> dcnt;
+  // staging in the handle (grown geometrically, never per call): [accum n | xy 2n] doubles, [indices cap] ints, one count.  One stream
+  // synchronisation per call: the count comes back through the pinned block, the indices behind it in the same stream order.
+  dgs::DevBuf<double>& din = h->fc_in;
+  dgs::DevBuf<int>& dout = h->fc_out;
+  dgs::DevBuf<long long>& dcnt = h->fc_cnt;
   const double* d_acc = accum_distance;
   const double* d_xy = xy;
   int* d_idx = indices;
-  const int64_t cap = on_device ? capacity : std::min<int64_t>(capacity, n);
-  int rc = DGS_OK;
+  const int64_t cap = on_device ? capacity : std::min<int64_t>(capacity, n);   // (indices are int32 keyframe numbers: n <= INT32_MAX was checked)
   if (dcnt.reserve(1) != hipSuccess) { h->err = "hipMalloc failed"; return DGS_ERR_HIP; }
+  if (ensure_pinned(h, 8192) != DGS_OK) return DGS_ERR_HIP;
+  long long* count = reinterpret_cast<long long*>(reinterpret_cast<char*>(h->pinned) + 4096);
+  *count = 0;
   if (!on_device) {
-    if (din.reserve((size_t)3 * n) != hipSuccess || dout.reserve((size_t)std::max<int64_t>(cap, 1)) != hipSuccess) { h->err = "hipMalloc failed"; rc = DGS_ERR_HIP; }
-    if (!rc && (hipMemcpyAsync(din.ptr, accum_distance, sizeof(double) * n, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-                hipMemcpyAsync(din.ptr + n, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, h->stream) != hipSuccess)) { h->err = "hipMemcpyAsync failed"; rc = DGS_ERR_HIP; }
+    if (din.reserve((size_t)3 * n) != hipSuccess || dout.reserve((size_t)std::max<int64_t>(cap, 1)) != hipSuccess) { h->err = "hipMalloc failed"; return DGS_ERR_HIP; }
+    DGS_HIP_TRY(h, hipMemcpyAsync(din.ptr, accum_distance, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    DGS_HIP_TRY(h, hipMemcpyAsync(din.ptr + n, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, h->stream));
     d_acc = din.ptr; d_xy = din.ptr + n; d_idx = dout.ptr;
   }
-  long long count = 0;
-  if (!rc) {
-    hipLaunchKernelGGL(find_candidates_kernel, dim3(1), dim3(1024), 0, h->stream, d_acc, d_xy, (long long)n, new_accum_distance, new_xy[0], new_xy[1],
-                       accum_distance_thresh, distance_thresh, d_idx, (long long)cap, dcnt.ptr);
-    if (hipMemcpyAsync(&count, dcnt.ptr, sizeof(count), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess ||
-        hipGetLastError() != hipSuccess) { h->err = "find_candidates_kernel failed"; rc = DGS_ERR_HIP; }
-  }
-  if (!rc) {
-    *n_out = count;
-    if (count > capacity) { h->err = "indices buffer too small for the candidates"; rc = DGS_ERR_INVALID_ARGUMENT; }
-    else if (!on_device && count > 0 && hipMemcpy(indices, d_idx, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "hipMemcpy failed"; rc = DGS_ERR_HIP; }
-  }
-  (void)hipStreamSynchronize(h->stream);
-  din.release(); dout.release(); dcnt.release();
-  return rc;
+  hipLaunchKernelGGL(find_candidates_kernel, dim3(1), dim3(1024), 0, h->stream, d_acc, d_xy, (long long)n, new_accum_distance, new_xy[0], new_xy[1],
+                     accum_distance_thresh, distance_thresh, d_idx, (long long)cap, dcnt.ptr);
+  DGS_HIP_TRY(h, hipMemcpyAsync(count, dcnt.ptr, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+  // the kernel writes at most `cap` indices whatever it counts: all of them travel now (a few hundred keyframes), the count says how many are meant
+  if (!on_device && cap > 0) DGS_HIP_TRY(h, hipMemcpyAsync(indices, d_idx, sizeof(int32_t) * (size_t)cap, hipMemcpyDeviceToHost, h->stream));
+  DGS_HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (hipGetLastError() != hipSuccess) { h->err = "find_candidates_kernel failed"; return DGS_ERR_HIP; }
+  *n_out = *count;
+  if (*count > capacity) { h->err = "indices buffer too small for the candidates"; return DGS_ERR_INVALID_ARGUMENT; }
+  return DGS_OK;
 }
 
 int dgs_calc_fitness_score(dgs_handle* h, const float* cloud1, int64_t n1, const float* cloud2, int64_t n2, int32_t on_device,

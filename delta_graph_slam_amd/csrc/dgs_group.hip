@@ -468,6 +468,25 @@ int32_t dgs_group_cloud_copies(const dgs_group_cloud* c) {
   return m;
 }
 
+int dgs_group_cloud_trim(dgs_group* g, dgs_group_cloud* c, int32_t owner) {
+  if (!g || !c || c->copy.size() != g->members.size()) return DGS_ERR_INVALID_ARGUMENT;
+  const int G = (int)c->copy.size();
+  int keep = owner >= 0 ? owner % G : -1;
+  if (keep < 0 || !c->copy[keep]) {
+    keep = -1;
+    for (int k = 0; k < G && keep < 0; k++)
+      if (c->copy[k]) keep = k;
+  }
+  if (keep < 0) return DGS_ERR_INVALID_ARGUMENT;
+  DeviceScope scope;
+  for (int k = 0; k < G; k++)
+    if (k != keep && c->copy[k]) {
+      dgs_cloud_destroy(c->copy[k]);
+      c->copy[k] = nullptr;
+    }
+  return DGS_OK;
+}
+
 int dgs_group_set_input_target_cloud(dgs_group* g, dgs_group_cloud* c) {
   if (!g || !c || c->copy.size() != g->members.size()) return DGS_ERR_INVALID_ARGUMENT;
   g->err.clear();

@@ -232,6 +232,10 @@ struct dgs_handle {
   // ---- calc_fitness_score between two arbitrary clouds (InformationMatrixCalculator): own buffers, the registration's
   // target / source / result are left untouched
   dgs::DevBuf<float4> aux_cloud1, aux_cloud2, aux_out;
+  // dgs_find_loop_candidates: staging kept across calls ([accum n | xy 2n], indices, count) -- the call is made every graph update
+  dgs::DevBuf<double> fc_in;
+  dgs::DevBuf<int> fc_out;
+  dgs::DevBuf<long long> fc_cnt;
   dgs::Bvh aux_bvh;
 
   // ---- GICP (fast_gicp::FastGICP): k-NN covariances of both clouds, correspondences, Mahalanobis matrices

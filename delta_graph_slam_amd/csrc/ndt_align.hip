@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
         const v2f u1 = q0 * Cxy + q1 * Cyy + q2 * Cyz;
         const v2f u2 = q0 * Cxz + q1 * Cyz + q2 * Czz;
         const v2f arg = -gd2 * (q0 * u0 + q1 * u1 + q2 * u2) * 0.5f;
-        v2f e = {exp_hw(arg.x), exp_hw(arg.y)};
+        v2f e = {expf(arg.x), expf(arg.y)};   // the library expf, as the default kernel (round 4)
         const float sia = (float)(-gd1 * (double)e.x), sib = (float)(-gd1 * (double)e.y);
         e = gd2 * e;
         const bool oka = va >= 0 && !(e.x > 1.f || e.x < 0.f || e.x != e.x), okb = vb >= 0 && !(e.y > 1.f || e.y < 0.f || e.y != e.y);
@@ -2100,7 +2100,8 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
   }
   hipEvent_t* ev = h->ev_poll;
   const int per_iter = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
-  const long max_evals = (long)(h->prm.maximum_iterations + 3) * per_iter + 2;
+  // (upstream order with speculated Newton steps: an evaluation whose header the exact step refuses is made again -- at most twice the launches)
+  const long max_evals = ((long)(h->prm.maximum_iterations + 3) * per_iter + 2) * ((h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM && h->ndt_speculate) ? 2 : 1);
   const int chunk = 4;  // (derivatives, solve) launches between two looks at the done counter
   long queued = 0;
   const bool fused = fused_flags;

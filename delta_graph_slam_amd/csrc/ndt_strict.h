@@ -102,114 +102,103 @@ __device__ __forceinline__ int strict_pick(const int (&vids)[NB], const int k) {
 
 // ---- kinds 0 / 1: updateDerivatives in float for ONE (point, voxel) item; acc = [score, g 0..5, H 0..35 row-major].
 // xt: the transformed point; xj / xh: the point's 8 + 15 products with the angle tables (computePointDerivatives).
+// Two halves, so that the item-compacted kernel can issue the NEXT item's voxel record between them (the Hessian block behind covers its L2 latency):
+// front = Mahalanobis term, exp, the weight test, gradient increments, the x^T C H vectors; back = the 36 Hessian increments and the score.
+struct StrictMid {
+  float C[3][3], cPG[3][3], g6[6], xch[6], e, score_inc;
+};
+
+// the 64-byte voxel record as four 16-byte words: mean (3 doubles), then the 9 floats of float(icov) row-major, one pad
+struct StrictRecWords {
+  float4 a, b, c, d;
+};
+__device__ __forceinline__ StrictRecWords strict_load_rec(const VoxelStrictRec* __restrict__ rec) {
+  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);
+  return StrictRecWords{r4[0], r4[1], r4[2], r4[3]};
+}
+
 template <bool NEED_H>
-__device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&xj)[8], const float (&xh)[15], const VoxelStrictRec* __restrict__ rec,
-                                            const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
+__device__ __forceinline__ bool strict_item_front(const float (&xt)[3], const float (&xj)[8], const float (&xh)[15], const StrictRecWords& w,
+                                                  const double gauss_d1, const float gd2, double (&acc)[kStrictAccum], StrictMid& m) {
   const float pg13 = xj[0], pg23 = xj[1];
   const float pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
-  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);
-  const float4 ra = r4[0], rb = r4[1], rc = r4[2], rd = r4[3];
+  const float4 ra = w.a, rb = w.b, rc = w.c, rd = w.d;
   const double m0 = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x)), m1 = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z)),
                m2 = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
   const float q0 = (float)((double)xt[0] - m0), q1 = (float)((double)xt[1] - m1), q2 = (float)((double)xt[2] - m2);
-  const float C[3][3] = {{rb.z, rb.w, rc.x}, {rc.y, rc.z, rc.w}, {rd.x, rd.y, rd.z}};
+  m.C[0][0] = rb.z; m.C[0][1] = rb.w; m.C[0][2] = rc.x;
+  m.C[1][0] = rc.y; m.C[1][1] = rc.z; m.C[1][2] = rc.w;
+  m.C[2][0] = rd.x; m.C[2][1] = rd.y; m.C[2][2] = rd.z;
   float qC[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) qC[c] = q0 * C[0][c] + q1 * C[1][c] + q2 * C[2][c];
+  for (int c = 0; c < 3; c++) qC[c] = q0 * m.C[0][c] + q1 * m.C[1][c] + q2 * m.C[2][c];
   float e = det_expf(-gd2 * (q0 * qC[0] + q1 * qC[1] + q2 * qC[2]) * 0.5f);
-  const float score_inc = (float)(-gauss_d1 * (double)e);
+  m.score_inc = (float)(-gauss_d1 * (double)e);
   e = gd2 * e;
-  if (e > 1 || e < 0 || e != e) return;
-  e = (float)((double)e * gauss_d1);
+  if (e > 1 || e < 0 || e != e) return false;
+  m.e = (float)((double)e * gauss_d1);
   // C * point gradient: columns 0..2 are C itself (unit columns), column 3 has a zero first factor
-  float cPG[3][3];   // columns 3, 4, 5
 #pragma unroll
   for (int r = 0; r < 3; r++) {
-    cPG[r][0] = C[r][1] * pg13 + C[r][2] * pg23;
-    cPG[r][1] = C[r][0] * pg4[0] + C[r][1] * pg4[1] + C[r][2] * pg4[2];
-    cPG[r][2] = C[r][0] * pg5[0] + C[r][1] * pg5[1] + C[r][2] * pg5[2];
+    m.cPG[r][0] = m.C[r][1] * pg13 + m.C[r][2] * pg23;
+    m.cPG[r][1] = m.C[r][0] * pg4[0] + m.C[r][1] * pg4[1] + m.C[r][2] * pg4[2];
+    m.cPG[r][2] = m.C[r][0] * pg5[0] + m.C[r][1] * pg5[1] + m.C[r][2] * pg5[2];
   }
-  float g6[6];
-  g6[0] = qC[0]; g6[1] = qC[1]; g6[2] = qC[2];   // q^T (C * unit column) is q^T C: the same operations
+  m.g6[0] = qC[0]; m.g6[1] = qC[1]; m.g6[2] = qC[2];   // q^T (C * unit column) is q^T C: the same operations
 #pragma unroll
-  for (int c = 0; c < 3; c++) g6[3 + c] = q0 * cPG[0][c] + q1 * cPG[1][c] + q2 * cPG[2][c];
+  for (int c = 0; c < 3; c++) m.g6[3 + c] = q0 * m.cPG[0][c] + q1 * m.cPG[1][c] + q2 * m.cPG[2][c];
 #pragma unroll
-  for (int c = 0; c < 6; c++) acc[1 + c] += (double)(e * g6[c]);
-#ifdef DGS_STRICT_PACKED_H   // A/B build (-DDGS_STRICT_PACKED_H): measured on the bench step 5.25-5.28 ms against 5.22 ms for the scalar form below -- the block shrinks from
-                            // 383 to 320 instructions (54 v_pk_mul_f32, 33 v_pk_add_f32, 19 moves), bit-identical results, no gain: at 2 waves per SIMD the
-                            // item loop waits on the voxel record's L2 latency and the LDS reads, not on issue slots
-  if (NEED_H) {
-    // The same 36 Hessian increments on PACKED FP32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE single operations per instruction, each component
-    // rounded on its own -- the same values as the scalar form below, operation for operation): entries (i, 2m) and (i, 2m + 1) of a row share
-    // an instruction.  Column pairs of J^T (C J_i): (cj0, cj1) | (cj2, pcp3) | (pcp4, pcp5), the last one from the point-gradient pairs
-    // (pg4[k], pg5[k]).
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    float xch[6];
-    xch[0] = qC[1] * xh[0] + qC[2] * xh[1];
-    xch[1] = qC[1] * xh[2] + qC[2] * xh[3];
-    xch[2] = qC[1] * xh[4] + qC[2] * xh[5];
-    xch[3] = qC[0] * xh[6] + qC[1] * xh[7] + qC[2] * xh[8];
-    xch[4] = qC[0] * xh[9] + qC[1] * xh[10] + qC[2] * xh[11];
-    xch[5] = qC[0] * xh[12] + qC[1] * xh[13] + qC[2] * xh[14];
-    const v2f G01 = {g6[0], g6[1]}, G23 = {g6[2], g6[3]}, G45 = {g6[4], g6[5]};
-    const v2f PG45_0 = {pg4[0], pg5[0]}, PG45_1 = {pg4[1], pg5[1]}, PG45_2 = {pg4[2], pg5[2]};
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const float ng = -gd2 * g6[i];
-      const float cj0 = (i < 3) ? C[0][i < 3 ? i : 0] : cPG[0][i < 3 ? 0 : i - 3];
-      const float cj1 = (i < 3) ? C[1][i < 3 ? i : 0] : cPG[1][i < 3 ? 0 : i - 3];
-      const float cj2 = (i < 3) ? C[2][i < 3 ? i : 0] : cPG[2][i < 3 ? 0 : i - 3];
-      v2f T01 = ng * G01, T23 = ng * G23, T45 = ng * G45;
-      if (i >= 3) {
-        // (i, 3), (i, 4), (i, 5): the vectors of the point Hessian's rotational block: (3,3) (3,4) (3,5) | (3,4) (4,4) (4,5) | (3,5) (4,5) (5,5)
-        const int r = i - 3;
-        const float x3 = xch[r == 0 ? 0 : (r == 1 ? 1 : 2)], x4 = xch[r == 0 ? 1 : (r == 1 ? 3 : 4)], x5 = xch[r == 0 ? 2 : (r == 1 ? 4 : 5)];
-        T23.y = T23.y + x3;
-        const v2f X45 = {x4, x5};
-        T45 = T45 + X45;
-      }
-      const v2f P01 = {cj0, cj1};
-      const v2f P23 = {cj2, pg13 * cj1 + pg23 * cj2};
-      const v2f P45 = PG45_0 * cj0 + PG45_1 * cj1 + PG45_2 * cj2;
-      const v2f V01 = e * (T01 + P01), V23 = e * (T23 + P23), V45 = e * (T45 + P45);
-      acc[7 + i * 6 + 0] += (double)V01.x; acc[7 + i * 6 + 1] += (double)V01.y;
-      acc[7 + i * 6 + 2] += (double)V23.x; acc[7 + i * 6 + 3] += (double)V23.y;
-      acc[7 + i * 6 + 4] += (double)V45.x; acc[7 + i * 6 + 5] += (double)V45.y;
-    }
-  }
-#else
+  for (int c = 0; c < 6; c++) acc[1 + c] += (double)(m.e * m.g6[c]);
   if (NEED_H) {
     // x^T C H for the six distinct vectors: a = (0, xh0, xh1) b = (0, xh2, xh3) c = (0, xh4, xh5) d = xh6..8 e = xh9..11 f = xh12..14
-    float xch[6];
-    xch[0] = qC[1] * xh[0] + qC[2] * xh[1];
-    xch[1] = qC[1] * xh[2] + qC[2] * xh[3];
-    xch[2] = qC[1] * xh[4] + qC[2] * xh[5];
-    xch[3] = qC[0] * xh[6] + qC[1] * xh[7] + qC[2] * xh[8];
-    xch[4] = qC[0] * xh[9] + qC[1] * xh[10] + qC[2] * xh[11];
-    xch[5] = qC[0] * xh[12] + qC[1] * xh[13] + qC[2] * xh[14];
+    m.xch[0] = qC[1] * xh[0] + qC[2] * xh[1];
+    m.xch[1] = qC[1] * xh[2] + qC[2] * xh[3];
+    m.xch[2] = qC[1] * xh[4] + qC[2] * xh[5];
+    m.xch[3] = qC[0] * xh[6] + qC[1] * xh[7] + qC[2] * xh[8];
+    m.xch[4] = qC[0] * xh[9] + qC[1] * xh[10] + qC[2] * xh[11];
+    m.xch[5] = qC[0] * xh[12] + qC[1] * xh[13] + qC[2] * xh[14];
+  }
+  return true;
+}
+
+// (A packed-FP32 form of this block -- v_pk_mul_f32 / v_pk_add_f32, entries (i, 2m) and (i, 2m + 1) of a row in one instruction, 383 -> 320
+//  instructions, bit-identical -- measured 5.25-5.28 ms on the bench step against 5.22 for this scalar form and was removed: the item loop was
+//  not bound by issue slots.)
+template <bool NEED_H>
+__device__ __forceinline__ void strict_item_back(const float (&xj)[8], const StrictMid& m, const float gd2, double (&acc)[kStrictAccum]) {
+  if (NEED_H) {
+    const float pg13 = xj[0], pg23 = xj[1];
+    const float pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
     // full C * J (3 x 6) as a lookup: column i < 3 -> C[r][i], else cPG[r][i - 3]
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-      const float ng = -gd2 * g6[i];
-      const float cj0 = (i < 3) ? C[0][i < 3 ? i : 0] : cPG[0][i < 3 ? 0 : i - 3];
-      const float cj1 = (i < 3) ? C[1][i < 3 ? i : 0] : cPG[1][i < 3 ? 0 : i - 3];
-      const float cj2 = (i < 3) ? C[2][i < 3 ? i : 0] : cPG[2][i < 3 ? 0 : i - 3];
+      const float ng = -gd2 * m.g6[i];
+      const float cj0 = (i < 3) ? m.C[0][i < 3 ? i : 0] : m.cPG[0][i < 3 ? 0 : i - 3];
+      const float cj1 = (i < 3) ? m.C[1][i < 3 ? i : 0] : m.cPG[1][i < 3 ? 0 : i - 3];
+      const float cj2 = (i < 3) ? m.C[2][i < 3 ? i : 0] : m.cPG[2][i < 3 ? 0 : i - 3];
 #pragma unroll
       for (int j = 0; j < 6; j++) {
-        float t = ng * g6[j];
+        float t = ng * m.g6[j];
         if (i >= 3 && j >= 3) {
           const int lo = (i < j ? i : j) - 3, hi = (i < j ? j : i) - 3;
-          t = t + xch[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+          t = t + m.xch[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
         }
         // J_j^T (C J_i): column j of J is a unit vector for j < 3 and has a zero first entry for j == 3
         const float pcp = (j == 0) ? cj0 : (j == 1) ? cj1 : (j == 2) ? cj2 : (j == 3) ? (pg13 * cj1 + pg23 * cj2)
                         : (j == 4) ? (pg4[0] * cj0 + pg4[1] * cj1 + pg4[2] * cj2) : (pg5[0] * cj0 + pg5[1] * cj1 + pg5[2] * cj2);
-        acc[7 + i * 6 + j] += (double)(e * (t + pcp));
+        acc[7 + i * 6 + j] += (double)(m.e * (t + pcp));
       }
     }
   }
-#endif
-  acc[0] += (double)score_inc;
+  acc[0] += (double)m.score_inc;
+}
+
+template <bool NEED_H>
+__device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&xj)[8], const float (&xh)[15], const VoxelStrictRec* __restrict__ rec,
+                                            const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
+  StrictMid m;
+  const StrictRecWords w = strict_load_rec(rec);
+  if (strict_item_front<NEED_H>(xt, xj, xh, w, gauss_d1, gd2, acc, m)) strict_item_back<NEED_H>(xj, m, gd2, acc);
 }
 
 // the point's products with the float angle tables (computePointDerivatives).  As in the default order's kernel: rows 5..7 of the first
@@ -465,7 +454,9 @@ __device__ DGS_CLOSE_INLINE void ndt_close_strict(NdtPair* st, const double* row
   __builtin_amdgcn_s_waitcnt(0xc07f);
   STRICT_STAMP(2)
   bool speculated = false;
-  ndt_advance<false, false, true>(st, st, s, c, writer, defer_solve, speculate, &speculated);
+  // (a redo takes ITS step exactly and publishes that: speculating again would yield the very header that was just refused, for ever --
+  //  seen on a 2,048-point planar pair whose rotation components of the step, ~1e-8 rad, differ in the 6th digit between the two solvers)
+  ndt_advance<false, false, true>(st, st, s, c, writer, defer_solve, speculate && !redo, &speculated);
   STRICT_STAMP(3)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -565,6 +556,70 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
 // float operation is the same (the same strict_item / strict_item_hd).  All three evaluation kinds run in ONE launch per round.
 // WITH_HD = false: the kernel serves the float kinds only (64-point tiles, a third of the LDS, no double tables in registers: three waves
 // per SIMD instead of two); the pairs waiting for kind 2 are served by ndt_strict_kernel<SEARCH, FUSED, HD = true> as the round's second launch.
+
+// The float items of one tile, 64 per round, lane <-> item.
+// A/B build `make ab AB=-DDGS_STRICT_ITEMS=1`: the loop software-pipelined by hand -- the NEXT round's queue entry read at the top, its voxel record
+// (four 16-byte gathers from L2) requested between the two halves of the current item, the 36-entry Hessian block behind covering the latency.
+// Measured on the bench step (same box, two runs each): 5.65 ms against 5.48 for the plain loop -- the 15 more live registers turn 4 spilled
+// registers into 29 in a kernel that sits at 256; the wave next door on the SIMD was hiding most of that latency already.  Not the default.
+template <bool NEED_H, int PTS>
+__device__ __forceinline__ void strict_items_float(const float* __restrict__ tf, const unsigned* __restrict__ queue, const int qn, const int lane,
+                                                   const VoxelStrictRec* __restrict__ vs, const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
+#if !defined(DGS_STRICT_ITEMS) || DGS_STRICT_ITEMS == 0   // the plain loop: the record loaded where it is used
+#pragma unroll 1
+  for (int h = 0; h < qn; h += 64) {
+    const int idx = h + lane;
+    if (idx < qn) {
+      const unsigned entry = queue[idx];
+      const int slot = (int)(entry >> 25);
+      float xt[3], xj[8], xh[15];
+#pragma unroll
+      for (int f = 0; f < 3; f++) xt[f] = tf[f * PTS + slot];
+#pragma unroll
+      for (int f = 0; f < 8; f++) xj[f] = tf[(3 + f) * PTS + slot];
+#pragma unroll
+      for (int f = 0; f < 15; f++) xh[f] = NEED_H ? tf[(11 + f) * PTS + slot] : 0.f;
+      strict_item<NEED_H>(xt, xj, xh, vs + (entry & 0x1FFFFFFu), gauss_d1, gd2, acc);
+    }
+  }
+#else
+  bool have = lane < qn;
+  unsigned entry = have ? queue[lane] : 0u;
+  StrictRecWords w = strict_load_rec(vs + (entry & 0x1FFFFFFu));   // (entry 0: voxel 0, a valid address; its words are not used)
+#pragma unroll 1
+  for (int h = 0; h < qn; h += 64) {
+    const int idx_n = h + 64 + lane;
+    const bool have_n = idx_n < qn;
+    const unsigned entry_n = have_n ? queue[idx_n] : 0u;
+    float xj[8];
+    StrictMid m;
+    bool alive = false;
+    if (have) {
+      const int slot = (int)(entry >> 25);
+      float xt[3], xh[15];
+#pragma unroll
+      for (int f = 0; f < 3; f++) xt[f] = tf[f * PTS + slot];
+#pragma unroll
+      for (int f = 0; f < 8; f++) xj[f] = tf[(3 + f) * PTS + slot];
+      if (NEED_H) {
+#pragma unroll
+        for (int f = 0; f < 15; f++) xh[f] = tf[(11 + f) * PTS + slot];
+      } else {
+#pragma unroll
+        for (int f = 0; f < 15; f++) xh[f] = 0.f;
+      }
+      alive = strict_item_front<NEED_H>(xt, xj, xh, w, gauss_d1, gd2, acc, m);
+    }
+    StrictRecWords wn = w;
+    if (have_n) wn = strict_load_rec(vs + (entry_n & 0x1FFFFFFu));
+    if (alive) strict_item_back<NEED_H>(xj, m, gd2, acc);
+    w = wn;
+    entry = entry_n;
+    have = have_n;
+  }
+#endif
+}
+
 template <int SEARCH, bool WITH_HD>
 struct StrictTile {
   static constexpr int NB = Offsets<SEARCH>::N;
@@ -592,7 +647,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
   // of a pair whose evaluation was published from the speculated direction (NdtPair::spec_s) runs beside the derivative work from the very
   // start of the launch; the remaining workgroups are dealt to the pairs of the round as ever.  A solver workgroup takes a ticket like a slice.
   const int n_solvers = (FUSED && speculate) ? n_pairs : 0;
-  const bool solver = (int)blockIdx.x < n_solvers;
+  const bool solver = FUSED && (int)blockIdx.x < n_solvers;   // (FUSED spelled out: the unfused kernels carry no solver role, tests/test_isa_handoff.py)
   auto in_round = [&](int pi) {
     return FUSED ? (launch <= pairs[pi].serve[0] || launch == pairs[pi].serve[2]) : (pairs[pi].active != 0 && (WITH_HD || pairs[pi].need_hessian != 2));
   };
@@ -708,13 +763,13 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     // ---- the items, 64 at a time
+    if (WITH_HD && kind == 2) {
 #pragma unroll 1
-    for (int h = 0; h < qn; h += 64) {
-      const int idx = h + lane;
-      if (idx < qn) {
-        const unsigned entry = queue[idx];
-        const int slot = (int)(entry >> 25), vid = (int)(entry & 0x1FFFFFFu);
-        if (WITH_HD && kind == 2) {
+      for (int h = 0; h < qn; h += 64) {
+        const int idx = h + lane;
+        if (idx < qn) {
+          const unsigned entry = queue[idx];
+          const int slot = (int)(entry >> 25), vid = (int)(entry & 0x1FFFFFFu);
           double xj[8], xh[15];
           float xt[3];
 #pragma unroll
@@ -724,23 +779,12 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
 #pragma unroll
           for (int f = 0; f < 3; f++) xt[f] = tdx[f * TL::PTS_HD + slot];
           (void)strict_item_hd<false>(xt, xj, xh, vtab + (size_t)vid * 12, gauss_d1, gauss_d2, acc, nullptr, 0);
-        } else {
-          float xt[3], xj[8], xh[15];
-#pragma unroll
-          for (int f = 0; f < 3; f++) xt[f] = tf[f * TL::PTS + slot];
-#pragma unroll
-          for (int f = 0; f < 8; f++) xj[f] = tf[(3 + f) * TL::PTS + slot];
-          if (kind == 1) {
-#pragma unroll
-            for (int f = 0; f < 15; f++) xh[f] = tf[(11 + f) * TL::PTS + slot];
-            strict_item<true>(xt, xj, xh, vs + vid, gauss_d1, gd2, acc);
-          } else {
-#pragma unroll
-            for (int f = 0; f < 15; f++) xh[f] = 0.f;
-            strict_item<false>(xt, xj, xh, vs + vid, gauss_d1, gd2, acc);
-          }
         }
       }
+    } else if (kind == 1) {
+      strict_items_float<true, TL::PTS>(tf, queue, qn, lane, vs, gauss_d1, gd2, acc);
+    } else {
+      strict_items_float<false, TL::PTS>(tf, queue, qn, lane, vs, gauss_d1, gd2, acc);
     }
     __builtin_amdgcn_wave_barrier();   // the next tile overwrites the tables and the queue (LDS operations of one wave stay in order)
   }

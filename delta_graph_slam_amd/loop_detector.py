@@ -22,6 +22,8 @@ from typing import Any, List, Optional, Sequence
 
 import time
 
+from collections import OrderedDict
+
 import numpy as np
 
 from .transforms import transform2Dto3D_batch, transform2Dto3D, transform3Dto2D
@@ -60,7 +62,7 @@ class Loop:
 
 class LoopDetector:
     def __init__(self, params: Optional[dict] = None, registration=None, group=None, device: Optional[int] = None,
-                 cache_clouds: bool = False, filter_on_device: bool = False):
+                 cache_clouds: bool = False, filter_on_device: bool = False, cache_capacity: Optional[int] = None):
         pr = dict(params or {})
         self.distance_thresh = float(pr.get("distance_thresh", 5.0))
         self.accum_distance_thresh = float(pr.get("accum_distance_thresh", 8.0))
@@ -77,8 +79,13 @@ class LoopDetector:
         # keyframe id -> DeviceCloud: a keyframe that is a candidate tick after tick (delta_graph_slam_nodelet.cpp:816 calls
         # detect() every graph_update_interval) is uploaded and indexed once; needs KeyFrame.id to be unique
         self.cache_clouds = bool(cache_clouds)
-        self.filter_on_device = bool(filter_on_device)   # find_candidates through dgs_find_loop_candidates (second half)
-        self._cloud_cache = {}
+        # find_candidates through dgs_find_loop_candidates (second half).  OFF by default: the call costs ~40 us whatever the
+        # graph holds (two small uploads, one workgroup, one synchronisation; scripts/r4_find_candidates_time.py on an MI355X: 39 us at 100-1,000
+        # keyframes, 74 us at 10,000, 0.33 ms at 100,000) -- the same two tests vectorised on the host take 5 / 17 / 129 us / 1.3 ms, and the
+        # reference's C++ loop a few ns per keyframe: it pays beyond ~5,000 keyframes here, or when the keyframe table already lives in HBM
+        self.filter_on_device = bool(filter_on_device)
+        self._cloud_cache = OrderedDict()         # least recently used first
+        self.cache_capacity = None if cache_capacity is None else max(1, int(cache_capacity))   # keyframes kept resident at most (None: all)
         self._exchange_buffers = {}
         self.exchange_seconds = 0.0   # host time spent in the exchange step (all-gather of the result records) since construction
         self.exchange_calls = 0
@@ -89,6 +96,8 @@ class LoopDetector:
         if not self.cache_clouds or keyframe.id < 0 or not hasattr(self.registration, "make_cloud"):
             return keyframe.cloud
         c = self._cloud_cache.get(keyframe.id)
+        if c is not None:
+            self._cloud_cache.move_to_end(keyframe.id)
         if c is None:
             if as_target or not hasattr(self.registration, "devices"):
                 c = self.registration.make_cloud(keyframe.cloud)
@@ -96,6 +105,20 @@ class LoopDetector:
                 c = self.registration.make_cloud(keyframe.cloud, owner=keyframe.id)
             self._cloud_cache[keyframe.id] = c
         return c
+
+    def _after_tick(self, new_keyframe: "KeyFrame", used_ids):
+        """Bounds what a tick leaves in HBM.  On a group the new keyframe was every member's target (one copy per member, cloned device to
+        device by dgs_group_set_input_target_cloud): as a candidate of later ticks it needs the copy on its owner only, so the others go
+        now.  And with a capacity set, the least recently used keyframes beyond it are released -- never one this tick used."""
+        c = self._cloud_cache.get(new_keyframe.id) if new_keyframe.id >= 0 else None
+        if c is not None and hasattr(c, "trim"):
+            c.trim(owner=new_keyframe.id)
+        if self.cache_capacity is not None and len(self._cloud_cache) > self.cache_capacity:
+            keep = set(used_ids)
+            for kid in [k for k in self._cloud_cache if k not in keep]:
+                if len(self._cloud_cache) <= self.cache_capacity:
+                    break
+                self.evict(kid)
 
     def evict(self, keyframe_id: int):
         c = self._cloud_cache.pop(keyframe_id, None)
@@ -181,6 +204,8 @@ class LoopDetector:
                     rec[j, 2] = r["fitness"]
                     rec[j, 3] = r.get("status", 0)
                     rec[j, 4:20] = np.asarray(r["T"], np.float64).reshape(16)
+        if self.cache_clouds:
+            self._after_tick(new_keyframe, [new_keyframe.id] + [candidates[c].id for c in mine])
         if world == 1 and not self.force_exchange:
             allrec = rec
         else:

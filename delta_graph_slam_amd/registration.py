@@ -434,6 +434,7 @@ class GroupCloud:
         if dev:
             raise ValueError("a group cloud is uploaded from the host (KeyFrame::cloud)")
         self._lib = group._lib
+        self._group = group
         self._c = C.c_void_p()
         group._check(self._lib.dgs_group_cloud_create(group._g, ptr, n, -1 if owner is None or owner < 0 else int(owner), C.byref(self._c)))
         self.n = n
@@ -444,6 +445,11 @@ class GroupCloud:
     @property
     def copies(self) -> int:
         return int(self._lib.dgs_group_cloud_copies(self._c))
+
+    def trim(self, owner: int = -1):
+        """dgs_group_cloud_trim: keep the copy on member owner mod G (or the first holder's), drop the others -- a keyframe that was every
+        member's target for a tick goes back to one copy on its owner."""
+        self._group._check(self._lib.dgs_group_cloud_trim(self._group._g, self._c, int(owner)))
 
     def close(self):
         if getattr(self, "_c", None) is not None and self._c.value:
@@ -543,12 +549,24 @@ class RegistrationGroup:
             ga = np.asarray(guesses, dtype=np.float32)
             g = np.ascontiguousarray(ga.transpose(0, 2, 1).reshape(n, 16)) if ga.ndim == 3 else np.ascontiguousarray(np.stack([_col16(G) for G in guesses]))
             gp = g.ctypes.data_as(C.c_void_p)
+        temps = []
+        if n and any(isinstance(s_, GroupCloud) for s_ in sources) and not all(isinstance(s_, GroupCloud) for s_ in sources):
+            # a mixed list (a keyframe without an id among cached ones): the raw clouds are uploaded for this call, candidate c to member c mod G
+            sources = list(sources)
+            for i, s_ in enumerate(sources):
+                if not isinstance(s_, GroupCloud):
+                    sources[i] = GroupCloud(self, s_, owner=i)
+                    temps.append(sources[i])
         if n and all(isinstance(s_, GroupCloud) for s_ in sources):   # resident keyframes: nothing is uploaded
             cl = (C.c_void_p * n)(*[s_._c.value for s_ in sources])
             res = (L.Result * n)()
             bi = C.c_int32(-1)
             bs = C.c_double(0)
-            self._check(self._lib.dgs_group_align_batch_clouds(self._g, n, cl, gp, 1 if compute_fitness else 0, fitness_max_range, res, C.byref(bi), C.byref(bs)))
+            try:
+                self._check(self._lib.dgs_group_align_batch_clouds(self._g, n, cl, gp, 1 if compute_fitness else 0, fitness_max_range, res, C.byref(bi), C.byref(bs)))
+            finally:
+                for t in temps:
+                    t.close()
             self.best_index, self.best_score = bi.value, bs.value
             return res
         ptrs = (C.c_void_p * n)()

@@ -65,8 +65,16 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
   void setNeighborhoodSearchMethod(int method) { params_.ndt_search_method = method; dirty_ = true; }  // dgs_ndt_search == pclomp order
   void setCorrespondenceRandomness(int k) { params_.gicp_correspondence_randomness = k; dirty_ = true; }
   void setStepSize(double s) { params_.ndt_step_size = s; dirty_ = true; }
-  // dgs_ndt_strict_order: 0 fast (default), 1 upstream operation order, 2 + index-order sums (validation modes, dgs_reg.h)
+  // dgs_ndt_strict_order: 0 fast (re-associated, opt-in), 1 upstream operation order (default), 2 + index-order sums (validation, dgs_reg.h)
   void setNdtStrictOrder(int order) { params_.ndt_strict_order = order; dirty_ = true; }
+  // the pieces of the upstream order, one by one (all on by default; dgs_reg.h): Eigen's two-sided JacobiSVD sequence for the Newton
+  // step, PCL's double computeHessian after a line search, the guess's rotation as Affine3f::rotation() takes it
+  void setNdtUpstreamFidelity(bool jacobi_svd, bool hessian_double, bool guess_polar) {
+    params_.ndt_newton_solver = jacobi_svd;
+    params_.ndt_hessian_recompute_double = hessian_double;
+    params_.ndt_guess_rotation_polar = guess_polar;
+    dirty_ = true;
+  }
   void setOulierRatio(double r) { params_.ndt_outlier_ratio = r; dirty_ = true; }  // (sic) upstream spelling
   void setRotationEpsilon(double e) { params_.gicp_rotation_epsilon = e; dirty_ = true; }
   void setRegularizationMethod(int m) { params_.gicp_regularization = m; dirty_ = true; }

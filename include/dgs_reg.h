@@ -67,10 +67,11 @@ enum dgs_ndt_search { DGS_NDT_KDTREE = 0, DGS_NDT_DIRECT26 = 1, DGS_NDT_DIRECT7 
  *   Kept because un-pinned ndt_omp forks differ here; it oscillates on planar scenes (DESIGN.md "NDT sensitivity"). */
 enum dgs_ndt_line_search { DGS_NDT_LS_FIXED_STEP = 0, DGS_NDT_LS_MORE_THUENTE = 1 };
 
-/* Order of the per-point arithmetic of NDT computeDerivatives / updateDerivatives (validation modes; DESIGN.md "Parity").
- * FAST (default): the <= 7 voxels of a point are folded in float and projected once through the point Jacobian (1/3 of the
- *   flops, FMA contraction allowed, hardware expf, Gauss-Jordan Newton solve): the same algebra as upstream, re-associated.
- * UPSTREAM: every float operation of upstream's per-voxel update in upstream's order, individually rounded (no FMA), a
+/* Order of the per-point arithmetic of NDT computeDerivatives / updateDerivatives (DESIGN.md "Parity").
+ * FAST: the <= 7 voxels of a point are folded in float and projected once through the point Jacobian (1/3 of the
+ *   flops, FMA contraction allowed, the library expf, Gauss-Jordan Newton solve): the same algebra as upstream, re-associated.
+ *   Opt-in: 2.4 x the throughput of UPSTREAM, a few ill-conditioned pairs per 32 land outside 1e-4 m of a CPU run.
+ * UPSTREAM (default since ABI 5): every float operation of upstream's per-voxel update in upstream's order, individually rounded (no FMA), a
  *   platform-independent exp, each voxel's increments added to the point's double totals, the full (not exactly symmetric)
  *   6x6 Hessian, Jacobi-SVD Newton solve; the points' totals are summed in the GPU's own fixed order, so only the order of
  *   the double summation differs from a CPU run of upstream.
@@ -105,7 +106,7 @@ typedef struct dgs_params {
   int32_t ndt_line_search;          /* dgs_ndt_line_search, default DGS_NDT_LS_MORE_THUENTE */
   int32_t ndt_mt_max_step_iterations; /* default 10 */
   int32_t ndt_fix_hessian_d1;       /* 0 = upstream h_ang_d1 table (z-term +sy); 1 = exact (-sy) */
-  int32_t ndt_strict_order;         /* dgs_ndt_strict_order, default DGS_NDT_ORDER_FAST */
+  int32_t ndt_strict_order;         /* dgs_ndt_strict_order, default DGS_NDT_ORDER_UPSTREAM */
 
   /* ---- GICP (fast_gicp::FastGICP) ---- */
   double gicp_max_correspondence_distance; /* setMaxCorrespondenceDistance; factory default 2.5 (registrations.cpp:33) */
@@ -288,6 +289,11 @@ int dgs_group_cloud_create(dgs_group* g, const float* xyz16, int64_t n, int32_t 
 void dgs_group_cloud_destroy(dgs_group_cloud* cloud);
 int64_t dgs_group_cloud_size(const dgs_group_cloud* cloud);
 int32_t dgs_group_cloud_copies(const dgs_group_cloud* cloud);   /* members that hold a copy */
+/* Drops every copy but ONE: the one on member `owner mod G` when that member holds one, else the first holder's (owner < 0: the first
+ * holder's).  A new keyframe is every member's target for one tick (dgs_group_set_input_target_cloud leaves a copy on every member); as
+ * a candidate of later ticks it needs the one copy on its owner only -- the caller trims it when the tick is over.  A copy still bound to
+ * its member as target or source is detached like in dgs_cloud_destroy. */
+int dgs_group_cloud_trim(dgs_group* g, dgs_group_cloud* cloud, int32_t owner);
 int dgs_group_set_input_target_cloud(dgs_group* g, dgs_group_cloud* cloud);
 int dgs_group_align_batch_clouds(dgs_group* g, int32_t n, dgs_group_cloud* const* sources, const float* guesses16, int32_t compute_fitness,
                                  double fitness_max_range, dgs_result* results, int32_t* best_index, double* best_score);

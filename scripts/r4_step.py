@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--points", type=int, default=65536)
     ap.add_argument("--seed", type=int, default=40)
     ap.add_argument("--profile", action="store_true", help="second pass with the handle's HIP-event profiler on")
+    ap.add_argument("--evals", action="store_true", help="also print the evaluations of every pair (one more batch, host clouds)")
+    ap.add_argument("--lib", default=None, help="another build of the library (e.g. delta_graph_slam_amd/libdgs_reg_ab.so)")
     ap.add_argument("--kw", nargs="*", default=[])
     a = ap.parse_args()
     import torch
@@ -42,7 +44,10 @@ def main():
         est[:2, :2] = guesses[c][:2, :2]
         est[:2, 2] = guesses[c][:2, 3]
         cands.append(KeyFrame(cloud=torch.from_numpy(sources[c]).to(dev), estimate=est, accum_distance=0.0, id=1 + c))
+    if a.lib:
+        kw["lib_path"] = os.path.join(ROOT, a.lib) if not os.path.isabs(a.lib) else a.lib
     reg = Registration("NDT_OMP", device=0, **kw)
+    kw.pop("lib_path", None)
     det = LoopDetector({"fitness_score_thresh": 1e9}, registration=reg)
     for _ in range(a.warmup):
         det.matching(cands, new_kf)
@@ -62,6 +67,12 @@ def main():
             ms, n = reg.profile_get(k)
             out[name] = {"ms_per_step": ms / a.steps, "launches_per_step": n / a.steps, "us_per_launch": 1e3 * ms / max(n, 1)}
         reg.profile_enable(False)
+    if a.evals:   # evaluations per pair: how many pairs are still iterating in launch k of a step
+        reg.setInputTarget(tgt)
+        res = reg.align_batch(list(sources), guesses)
+        ev = sorted(x["evaluations"] for x in res)
+        out["evaluations_per_pair_sorted"] = ev
+        out["pairs_active_in_launch"] = [sum(e > k for e in ev) for k in range(max(ev))]
     print(json.dumps(out), flush=True)
 
 

@@ -68,6 +68,8 @@ def test_defaults_are_the_reference_factory_defaults():
         assert p.gicp_max_correspondence_distance == 2.5 and p.gicp_correspondence_randomness == 20
         assert p.gicp_regularization == L.GICP_REG["PLANE"] and p.gicp_rotation_epsilon == 2e-3
         assert p.vgicp_resolution == 1.0 and p.vgicp_search_method == L.VGICP_SEARCH["DIRECT1"]      # registrations.cpp:52, FastVGICP ctor
+        # the evaluation order that reproduces a CPU run of upstream is the default (ABI 5); the re-associated fast order is opt-in
+        assert p.ndt_strict_order == 1 and p.ndt_newton_solver == 1 and p.ndt_hessian_recompute_double == 1 and p.ndt_guess_rotation_polar == 1
     assert lib.dgs_params_init(C.byref(L.Params()), 7) == 1      # unknown method: DGS_ERR_INVALID_ARGUMENT
     assert lib.dgs_params_init(None, 0) == 1
 

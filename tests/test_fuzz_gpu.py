@@ -54,7 +54,7 @@ def _cases(count, seed):
 def test_ndt_derivatives_sweep(oracle_lib):
     from delta_graph_slam_amd import _lib as L
     from delta_graph_slam_amd.registration import Registration
-    worst = 0.0
+    worst, n_aligned = 0.0, 0
     for c, rng, tgt, src, T in _cases(48 * SCALE, 11):
         res = float(rng.choice([0.5, 0.8, 1.0, 1.7, 2.0]))
         search = str(rng.choice(["DIRECT7", "DIRECT1", "DIRECT26", "KDTREE"]))
@@ -66,7 +66,8 @@ def test_ndt_derivatives_sweep(oracle_lib):
         o = oracle_lib.NdtOracle(resolution=res, search_method=search)
         o.set_target(clean)
         o.set_source(src)
-        r = Registration("NDT_OMP", ndt_resolution=res, ndt_search_method=L.NDT_SEARCH[search])
+        order = c % 2             # odd scenes: the default (upstream) order, even scenes: the opt-in fast order
+        r = Registration("NDT_OMP", ndt_resolution=res, ndt_search_method=L.NDT_SEARCH[search], ndt_strict_order=order)
         r.setInputTarget(tgt)
         r.setInputSource(src)
         for _ in range(2):
@@ -81,7 +82,12 @@ def test_ndt_derivatives_sweep(oracle_lib):
         # the align itself must terminate and report a transform near the truth or not converged -- never garbage
         r.align(T.astype(np.float32))
         assert np.isfinite(r.getFinalTransformation()).all()
-    assert worst < 2e-5
+        if order == 1:            # and in upstream's operation order the final pose is the oracle's, scene after scene (north_star's gate)
+            ro = o.align(T.astype(np.float32))
+            dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+            assert r.hasConverged() == ro["converged"] and dt <= TOL_TRANS and dr <= TOL_ROT, (c, res, search, dt, dr)
+            n_aligned += 1
+    assert worst < 2e-5 and n_aligned == 24 * SCALE
 
 
 @pytest.mark.parametrize("method", ["FAST_GICP", "FAST_VGICP"])

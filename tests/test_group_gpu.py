@@ -27,7 +27,8 @@ def _same(a, b):
         assert x["fitness"] == y["fitness"] and x["status"] == y["status"] == 0
 
 
-@pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("FAST_GICP", dict(gicp_max_correspondence_distance=2.0))])
+@pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("NDT_OMP", dict(ndt_resolution=1.0, ndt_strict_order=0)),
+                                       ("FAST_GICP", dict(gicp_max_correspondence_distance=2.0))])
 def test_group_of_one_device_equals_align_batch_and_gathers_with_rccl(batch, method, kw):
     from delta_graph_slam_amd.registration import Registration, RegistrationGroup
     tgt, sources, guesses, _ = batch
@@ -114,7 +115,8 @@ def test_group_of_eight_members_with_more_and_fewer_candidates_than_members():
 
 
 # ---- keyframe clouds resident on the group's devices (dgs_group_cloud_*, include/dgs_reg.h) ------------------------------------
-@pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("FAST_GICP", dict(gicp_max_correspondence_distance=2.0))])
+@pytest.mark.parametrize("method,kw", [("NDT_OMP", dict(ndt_resolution=1.0)), ("NDT_OMP", dict(ndt_resolution=1.0, ndt_strict_order=0)),
+                                       ("FAST_GICP", dict(gicp_max_correspondence_distance=2.0))])
 def test_group_of_one_device_with_resident_clouds_equals_align_batch_clouds(batch, method, kw):
     """group{0}: resident keyframes, records written on the device and exchanged with ncclAllGather == dgs_align_batch_clouds"""
     from delta_graph_slam_amd.registration import Registration, RegistrationGroup
@@ -184,7 +186,39 @@ def test_loop_detector_caches_keyframes_on_a_group(batch):
         assert np.array_equal(d1.last_records[:, 1:], d2.last_records[:, 1:])
         assert (l1 is None) == (l2 is None) and (l1 is None or (l1.key2.id == l2.key2.id and np.array_equal(l1.relative_pose, l2.relative_pose)))
     assert len(d2._cloud_cache) == 8 and all(isinstance(c, GroupCloud) for c in d2._cloud_cache.values())
-    assert d2._cloud_cache[100].copies == 2 and d2._cloud_cache[3].copies == 1
+    assert d2._cloud_cache[100].copies == 1 and d2._cloud_cache[3].copies == 1   # the target was on both members during the tick, trimmed to its owner's after it
+
+
+def test_group_cloud_trim_and_mixed_candidate_lists(batch):
+    """dgs_group_cloud_trim: a replicated keyframe goes back to ONE copy (its owner's) and still serves as a candidate and, promoted again, as
+    a target; a candidate list that mixes resident keyframes with raw clouds (a keyframe without an id) is served, the raw ones uploaded for the
+    call -- all equal to the single handle's records."""
+    from delta_graph_slam_amd.registration import Registration, RegistrationGroup
+    tgt, sources, guesses, _ = batch
+    r = Registration("NDT_OMP", ndt_resolution=1.0)
+    r.setInputTarget(tgt)
+    ref = r.align_batch(sources, guesses)
+    g = RegistrationGroup("NDT_OMP", devices=[0, 0, 0], ndt_resolution=1.0)
+    gt = g.make_cloud(tgt)
+    assert gt.copies == 3
+    g.setInputTarget(gt)
+    kf = [g.make_cloud(s, owner=i) for i, s in enumerate(sources)]
+    _same(g.align_batch(kf, guesses), ref)
+    gt.trim(owner=7)                                      # member 7 mod 3 = 1 keeps its copy; the members it was bound to as target let go of it
+    assert gt.copies == 1
+    gt.trim(owner=7)                                      # idempotent
+    assert gt.copies == 1
+    g.setInputTarget(gt)                                  # promoted again: cloned device to device from the one holder
+    assert gt.copies == 3
+    mixed = [kf[0], sources[1], kf[2], sources[3], sources[4], kf[5], kf[6]]
+    _same(g.align_batch(mixed, guesses), ref)
+    r.setInputTarget(sources[2])
+    g.setInputTarget(kf[2])
+    kf[2].trim(owner=2)
+    assert kf[2].copies == 1
+    g.setInputTarget(kf[2])
+    _same(g.align_batch([gt, kf[0]], guesses[[0, 1]]), r.align_batch([tgt, sources[0]], guesses[[0, 1]]))   # the trimmed ex-target as a candidate
+    g.close()
 
 
 def test_cfg4_at_its_full_candidate_count_256_candidates_over_8_members(oracle_lib):

@@ -165,6 +165,57 @@ def test_record_path_equals_dict_path():
     assert LoopDetector.select_best(ra)[0] == LoopDetector.select_best(rb)[0]
 
 
+def test_keyframe_cache_is_bounded_and_a_group_target_goes_back_to_one_copy():
+    """LoopDetector(cache_clouds=True): after a tick the new keyframe -- every member's target on a group -- is trimmed to the copy on its owner,
+    and with cache_capacity set the least recently used keyframes beyond it are released, never one the tick used (host logic; the device
+    side of trim / mixed lists is tests/test_group_gpu.py)."""
+    from delta_graph_slam_amd.loop_detector import KeyFrame, LoopDetector, RECORD_WIDTH
+    log = []
+
+    class Cloud:
+        def __init__(self, owner):
+            self.owner, self.closed = owner, False
+
+        def trim(self, owner=-1):
+            log.append(("trim", owner))
+
+        def close(self):
+            self.closed = True
+            log.append(("close", self.owner))
+
+    class Group:
+        devices = [0, 1]
+
+        def make_cloud(self, cloud, owner=None):
+            return Cloud(owner)
+
+        def setInputTarget(self, cloud):
+            self.target = cloud
+
+        def align_batch_records(self, sources, guesses=None, compute_fitness=True, fitness_max_range=0.0):
+            out = np.full((len(sources), RECORD_WIDTH), -1.0)
+            out[:, 1] = 1.0
+            out[:, 2] = np.arange(len(sources)) + 1.0
+            out[:, 3] = 0
+            out[:, 4:20] = np.eye(4).reshape(16)
+            return out
+
+    kf = lambda i, acc: KeyFrame(np.zeros((1, 4), np.float32), np.eye(3), acc, i)
+    det = LoopDetector({}, registration=Group(), cache_clouds=True, cache_capacity=4)
+    det.register_shard([kf(1, 0.0), kf(2, 0.0), kf(3, 0.0)], kf(10, 50.0))
+    assert ("trim", 10) in log and list(det._cloud_cache) == [1, 2, 3, 10]        # 4 resident: at capacity, nothing released
+    assert det._cloud_cache[10].owner is None and det._cloud_cache[2].owner == 2   # target on every member, candidates on their owners
+    log.clear()
+    det.register_shard([kf(3, 0.0), kf(10, 50.0), kf(4, 0.0)], kf(11, 60.0))      # keyframe 10 is a candidate now: served from the cache
+    assert ("trim", 11) in log
+    assert sorted(det._cloud_cache) == [3, 4, 10, 11] and ("close", 1) in log and ("close", 2) in log   # the two least recently used went
+    assert not det._cloud_cache[10].closed
+    log.clear()
+    det.cache_capacity = 2
+    det.register_shard([kf(3, 0.0), kf(10, 50.0), kf(4, 0.0)], kf(12, 70.0))      # a tick that uses 4 keyframes keeps all 4: only 11 can go
+    assert sorted(det._cloud_cache) == [3, 4, 10, 12] and log.count(("close", None)) == 1
+
+
 def test_factory_refuses_the_reference_branches_it_does_not_serve():
     """registrations.cpp:59-100: ICP / GICP / GICP_OMP / plain NDT / FAST_VGICP_CUDA are other algorithms -- never silently replaced."""
     from delta_graph_slam_amd.registration import Registration, select_registration_method

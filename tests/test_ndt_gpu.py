@@ -8,10 +8,17 @@ from tests.helpers import TOL_ROT, TOL_TRANS, f32_sqdist, f32_transform, pose_er
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def reg_cls():
+@pytest.fixture(scope="module", params=[1, 0], ids=["upstream_order", "fast_order"])
+def reg_cls(request):
+    """The registration factory with the NDT evaluation order pinned: every test of this file runs in the default (upstream) order and
+    in the opt-in fast order, against the same oracle numbers and the same tolerances."""
     from delta_graph_slam_amd.registration import Registration
-    return Registration
+
+    def make(method, **kw):
+        if method == "NDT_OMP":
+            kw.setdefault("ndt_strict_order", request.param)
+        return Registration(method, **kw)
+    return make
 
 
 def _pair(reg_cls, oracle_lib, tgt, src, **kw):

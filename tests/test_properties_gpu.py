@@ -246,7 +246,8 @@ def test_very_wide_batch(method):
         assert abs(res[k, 2] - single.getFitnessScore()) <= 1e-6 * abs(res[k, 2])
 
 
-def test_fused_launches_equal_launch_pairs_bit_for_bit(scans):
+@pytest.mark.parametrize("order", [0, 1])
+def test_fused_launches_equal_launch_pairs_bit_for_bit(scans, order):
     """The closing workgroup of a fused launch (DGS_NDT_FUSED=1, default) sums the same rows in the same order as ndt_solve_kernel:
     transforms, scores, iteration counts and trajectories must be bit-identical to the two-launch form, run after run (a stale row
     read through the in-launch hand-off would show up as a difference)."""
@@ -258,7 +259,7 @@ def test_fused_launches_equal_launch_pairs_bit_for_bit(scans):
         old = os.environ.get("DGS_NDT_FUSED")
         os.environ["DGS_NDT_FUSED"] = fused
         try:
-            return Registration("NDT_OMP", ndt_resolution=1.0)
+            return Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=order)
         finally:
             if old is None:
                 del os.environ["DGS_NDT_FUSED"]
@@ -275,9 +276,17 @@ def test_fused_launches_equal_launch_pairs_bit_for_bit(scans):
     for _ in range(4):
         got = a.align_batch(src, gs)
         for c, (x, y) in enumerate(zip(got, ref)):
-            assert np.array_equal(x["T"], y["T"]) and x["score"] == y["score"] and x["iterations"] == y["iterations"] and x["evaluations"] == y["evaluations"], c
+            assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"] and x["evaluations"] == y["evaluations"], c
             assert x["fitness"] == y["fitness"]
-        assert np.array_equal(a.ndt_trajectory(5), b.ndt_trajectory(5))
+            if order == 0:
+                assert x["score"] == y["score"], c
+            else:   # upstream order: the unfused launch deals its workgroups over the pairs still active, the fused one by NdtPair::serve --
+                #     another (fixed) partition of the double sums per launch structure: the last bits of a score may differ, the floats of T not
+                assert abs(x["score"] - y["score"]) <= 1e-13 * abs(y["score"]), c
+        if order == 0:
+            assert np.array_equal(a.ndt_trajectory(5), b.ndt_trajectory(5))
+        else:
+            assert np.abs(a.ndt_trajectory(5) - b.ndt_trajectory(5)).max() <= 1e-12
 
 
 def test_packed_fp32_derivative_path_matches_the_default(scans):
@@ -290,13 +299,13 @@ def test_packed_fp32_derivative_path_matches_the_default(scans):
     os.environ["DGS_NDT_PACK2"] = "1"
     try:
         from delta_graph_slam_amd import _lib as L
-        p = Registration("NDT_OMP", ndt_resolution=1.0, lib_path=L.EXPERIMENTS_LIB_PATH)   # the kernel lives in the experiments build only
+        p = Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=0, lib_path=L.EXPERIMENTS_LIB_PATH)   # the kernel lives in the experiments build only (fast order)
     finally:
         if old is None:
             del os.environ["DGS_NDT_PACK2"]
         else:
             os.environ["DGS_NDT_PACK2"] = old
-    d = Registration("NDT_OMP", ndt_resolution=1.0)
+    d = Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=0)
     for r in (p, d):
         r.setInputTarget(tgt)
         r.setInputSource(sources[0][:65001])          # odd count: the second point of the last pair is missing

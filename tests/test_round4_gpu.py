@@ -141,3 +141,43 @@ def test_wave_parallel_jacobi_svd_step_is_the_oracles(oracle_lib, scene):
         r.align()
         t = r.ndt_trajectory()
         assert len(t) >= 2 and np.array_equal(t[:3], ro["trajectory"][:3]), (scene, solver)
+
+
+def test_refused_speculated_step_is_taken_again_exactly(oracle_lib):
+    """The default launch structure publishes the next evaluation from the Gauss-Jordan direction and lets a solver workgroup verify it against
+    the exact Jacobi-SVD step (NdtPair::spec_s).  On small planar pairs at the factory resolution the rotation components of the first Newton
+    step are ~1e-8 rad and ill-determined (cond(H) 2e5): the two solvers differ in their 6th digit, the float header differs, the verdict is
+    "refused" -- at the very first step, deterministically.  The closing must then take the step exactly and go on (a closing that speculated
+    again published the same refused header for ever: the pair ran out of launches, converged = 0 -- found when the upstream order became the
+    default).  Records equal the oracle's and those of a handle that never speculates, in a batch with a pair that is never refused."""
+    from delta_graph_slam_amd.registration import Registration
+    tgt, src, _ = synth.planar_pair(n=2048)
+    big_t, big_s, _ = synth.planar_pair(n=4096)
+    o = oracle_lib.NdtOracle(resolution=0.5)
+    o.set_target(tgt)
+    sources = [src, src[:2000], src[:1024], src[:300]]
+    ref = []
+    for s in sources:
+        o.set_source(s)
+        ref.append(o.align())
+    assert ref[0]["converged"] and ref[0]["iterations"] >= 10
+    with _env(DGS_NDT_SPECULATE=0):
+        plain = Registration("NDT_OMP", ndt_strict_order=1)
+    spec = Registration("NDT_OMP", ndt_strict_order=1)
+    for r in (spec, plain):
+        r.setInputTarget(tgt)
+        res = r.align_batch(sources, None)
+        for c, (x, y) in enumerate(zip(res, ref)):
+            assert x["converged"] == y["converged"] and (x["iterations"], x["evaluations"]) == (y["iterations"], y["evaluations"]), (c, x["iterations"], y["iterations"])
+            assert np.array_equal(x["T"], y["T"]), c
+        r.setInputSource(src)             # dgs_align: one pair, 8 slices + its solver workgroup, which finishes last and closes the round itself
+        r.align()
+        assert r.hasConverged() and r.last_result.iterations == ref[0]["iterations"] and np.array_equal(r.getFinalTransformation(), ref[0]["T"])
+    o2 = oracle_lib.NdtOracle(resolution=0.5)
+    o2.set_target(big_t)
+    o2.set_source(big_s)
+    rb = o2.align()
+    spec.setInputTarget(big_t)
+    spec.setInputSource(big_s)
+    spec.align()
+    assert spec.last_result.iterations == rb["iterations"] and np.array_equal(spec.getFinalTransformation(), rb["T"])
