@@ -38,7 +38,7 @@ class Params(C.Structure):
         ("gicp_regularization", C.c_int32), ("gicp_optimizer", C.c_int32), ("gicp_lm_max_iterations", C.c_int32),
         ("vgicp_search_method", C.c_int32), ("vgicp_resolution", C.c_double),
         ("ndt_newton_solver", C.c_int32), ("ndt_hessian_recompute_double", C.c_int32), ("ndt_guess_rotation_polar", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("ndt_exp_glibc", C.c_int32),
     ]
 
 

@@ -183,6 +183,7 @@ struct NdtConsts {
   int strict_order;  // dgs_ndt_strict_order
   int newton_solver;     // upstream orders: 1 = Eigen's two-sided JacobiSVD sequence (solve6.h jsvd_solve6_wave), 0 = one-sided Hestenes Jacobi
   int hessian_double;    // upstream orders: computeStepLengthMT's closing computeHessian in PCL's double form (evaluation kind 2)
+  int exp_libm;          // upstream orders: updateDerivatives' std::exp(float) as glibc computes it (glibc_expf_dev), 0 = det_expf (rounds 1-3)
 };
 
 struct NdtInit {  // host -> device per pair, per align
@@ -341,6 +342,30 @@ __device__ __forceinline__ float det_expf(float xf) {
   const long long k = (long long)kd;
   const double s = __longlong_as_double((k + 1023) << 52);  // 2^k, k in [-151, 129]: a normal double
   return (float)(p * s);
+}
+// std::exp(float) as glibc >= 2.27 computes it on an FMA-capable x86-64 (sysdeps/ieee754/flt-32/e_expf.c: x N / ln2 = k + r, N = 32, a table of
+// 2^(i/32), a cubic in r, all in double, one rounding to float): the exponential of upstream's updateDerivatives bit for bit -- the CPU checker
+// carries the same sequence and compares IT with its libm on every float in [-104, 0].  `tab`: the 32 table words (kGlibcExp2fTab, or a copy in LDS).
+__device__ __forceinline__ float glibc_expf_dev(float xf, const unsigned long long* __restrict__ tab) {
+#pragma clang fp contract(off)
+  if (xf != xf) return xf;
+  if (xf > 0x1.62e42ep6f) return __builtin_inff();
+  if (xf < -0x1.9fe368p6f) return 0.0f;
+  constexpr double N = 32.0;
+  constexpr double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+  constexpr double kShift = 0x1.8p+52, kInvLn2N = 0x1.71547652b82fep+0 * N;
+  const double xd = (double)xf;
+  double kd = __builtin_fma(kInvLn2N, xd, kShift);
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= kShift;
+  const double r = __builtin_fma(kInvLn2N, xd, -kd);
+  const double s = __longlong_as_double((long long)(tab[ki & 31ull] + (ki << 47)));
+  const double z = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(z, r2, y);
+  y = y * s;
+  return (float)y;
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -500,6 +500,62 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
 // CPU checker operation for operation.  Only the default derivative kernel above lets the compiler fuse multiply-adds.
 #pragma clang fp contract(off)
 
+// glibc's __exp_data.tab (N = 128): [2 i] = asuint64(tail_i), [2 i + 1] = asuint64(scale_i) - (i << 45), 2^(i/128) = scale_i (1 + tail_i); generated
+// from 2^(i/128) at 120 decimal digits (glibc_exp_dev, ndt_strict.h)
+__constant__ unsigned long long kGlibcExpTab[256] = {
+    0x0000000000000000ull, 0x3ff0000000000000ull, 0x3c9b3b4f1a88bf6eull, 0x3feff63da9fb3335ull, 0xbc7160139cd8dc5dull, 0x3fefec9a3e778061ull,
+    0xbc905e7a108766d1ull, 0x3fefe315e86e7f85ull, 0x3c8cd2523567f613ull, 0x3fefd9b0d3158574ull, 0xbc8bce8023f98efaull, 0x3fefd06b29ddf6deull,
+    0x3c60f74e61e6c861ull, 0x3fefc74518759bc8ull, 0x3c90a3e45b33d399ull, 0x3fefbe3ecac6f383ull, 0x3c979aa65d837b6dull, 0x3fefb5586cf9890full,
+    0x3c8eb51a92fdeffcull, 0x3fefac922b7247f7ull, 0x3c3ebe3d702f9cd1ull, 0x3fefa3ec32d3d1a2ull, 0xbc6a033489906e0bull, 0x3fef9b66affed31bull,
+    0xbc9556522a2fbd0eull, 0x3fef9301d0125b51ull, 0xbc5080ef8c4eea55ull, 0x3fef8abdc06c31ccull, 0xbc91c923b9d5f416ull, 0x3fef829aaea92de0ull,
+    0x3c80d3e3e95c55afull, 0x3fef7a98c8a58e51ull, 0xbc801b15eaa59348ull, 0x3fef72b83c7d517bull, 0xbc8f1ff055de323dull, 0x3fef6af9388c8deaull,
+    0x3c8b898c3f1353bfull, 0x3fef635beb6fcb75ull, 0xbc96d99c7611eb26ull, 0x3fef5be084045cd4ull, 0x3c9aecf73e3a2f60ull, 0x3fef54873168b9aaull,
+    0xbc8fe782cb86389dull, 0x3fef4d5022fcd91dull, 0x3c8a6f4144a6c38dull, 0x3fef463b88628cd6ull, 0x3c807a05b0e4047dull, 0x3fef3f49917ddc96ull,
+    0x3c968efde3a8a894ull, 0x3fef387a6e756238ull, 0x3c875e18f274487dull, 0x3fef31ce4fb2a63full, 0x3c80472b981fe7f2ull, 0x3fef2b4565e27cddull,
+    0xbc96b87b3f71085eull, 0x3fef24dfe1f56381ull, 0x3c82f7e16d09ab31ull, 0x3fef1e9df51fdee1ull, 0xbc3d219b1a6fbffaull, 0x3fef187fd0dad990ull,
+    0x3c8b3782720c0ab4ull, 0x3fef1285a6e4030bull, 0x3c6e149289cecb8full, 0x3fef0cafa93e2f56ull, 0x3c834d754db0abb6ull, 0x3fef06fe0a31b715ull,
+    0x3c864201e2ac744cull, 0x3fef0170fc4cd831ull, 0x3c8fdd395dd3f84aull, 0x3feefc08b26416ffull, 0xbc86a3803b8e5b04ull, 0x3feef6c55f929ff1ull,
+    0xbc924aedcc4b5068ull, 0x3feef1a7373aa9cbull, 0xbc9907f81b512d8eull, 0x3feeecae6d05d866ull, 0xbc71d1e83e9436d2ull, 0x3feee7db34e59ff7ull,
+    0xbc991919b3ce1b15ull, 0x3feee32dc313a8e5ull, 0x3c859f48a72a4c6dull, 0x3feedea64c123422ull, 0xbc9312607a28698aull, 0x3feeda4504ac801cull,
+    0xbc58a78f4817895bull, 0x3feed60a21f72e2aull, 0xbc7c2c9b67499a1bull, 0x3feed1f5d950a897ull, 0x3c4363ed60c2ac11ull, 0x3feece086061892dull,
+    0x3c9666093b0664efull, 0x3feeca41ed1d0057ull, 0x3c6ecce1daa10379ull, 0x3feec6a2b5c13cd0ull, 0x3c93ff8e3f0f1230ull, 0x3feec32af0d7d3deull,
+    0x3c7690cebb7aafb0ull, 0x3feebfdad5362a27ull, 0x3c931dbdeb54e077ull, 0x3feebcb299fddd0dull, 0xbc8f94340071a38eull, 0x3feeb9b2769d2ca7ull,
+    0xbc87deccdc93a349ull, 0x3feeb6daa2cf6642ull, 0xbc78dec6bd0f385full, 0x3feeb42b569d4f82ull, 0xbc861246ec7b5cf6ull, 0x3feeb1a4ca5d920full,
+    0x3c93350518fdd78eull, 0x3feeaf4736b527daull, 0x3c7b98b72f8a9b05ull, 0x3feead12d497c7fdull, 0x3c9063e1e21c5409ull, 0x3feeab07dd485429ull,
+    0x3c34c7855019c6eaull, 0x3feea9268a5946b7ull, 0x3c9432e62b64c035ull, 0x3feea76f15ad2148ull, 0xbc8ce44a6199769full, 0x3feea5e1b976dc09ull,
+    0xbc8c33c53bef4da8ull, 0x3feea47eb03a5585ull, 0xbc845378892be9aeull, 0x3feea34634ccc320ull, 0xbc93cedd78565858ull, 0x3feea23882552225ull,
+    0x3c5710aa807e1964ull, 0x3feea155d44ca973ull, 0xbc93b3efbf5e2228ull, 0x3feea09e667f3bcdull, 0xbc6a12ad8734b982ull, 0x3feea012750bdabfull,
+    0xbc6367efb86da9eeull, 0x3fee9fb23c651a2full, 0xbc80dc3d54e08851ull, 0x3fee9f7df9519484ull, 0xbc781f647e5a3ecfull, 0x3fee9f75e8ec5f74ull,
+    0xbc86ee4ac08b7db0ull, 0x3fee9f9a48a58174ull, 0xbc8619321e55e68aull, 0x3fee9feb564267c9ull, 0x3c909ccb5e09d4d3ull, 0x3feea0694fde5d3full,
+    0xbc7b32dcb94da51dull, 0x3feea11473eb0187ull, 0x3c94ecfd5467c06bull, 0x3feea1ed0130c132ull, 0x3c65ebe1abd66c55ull, 0x3feea2f336cf4e62ull,
+    0xbc88a1c52fb3cf42ull, 0x3feea427543e1a12ull, 0xbc9369b6f13b3734ull, 0x3feea589994cce13ull, 0xbc805e843a19ff1eull, 0x3feea71a4623c7adull,
+    0xbc94d450d872576eull, 0x3feea8d99b4492edull, 0x3c90ad675b0e8a00ull, 0x3feeaac7d98a6699ull, 0x3c8db72fc1f0eab4ull, 0x3feeace5422aa0dbull,
+    0xbc65b6609cc5e7ffull, 0x3feeaf3216b5448cull, 0x3c7bf68359f35f44ull, 0x3feeb1ae99157736ull, 0xbc93091fa71e3d83ull, 0x3feeb45b0b91ffc6ull,
+    0xbc5da9b88b6c1e29ull, 0x3feeb737b0cdc5e5ull, 0xbc6c23f97c90b959ull, 0x3feeba44cbc8520full, 0xbc92434322f4f9aaull, 0x3feebd829fde4e50ull,
+    0xbc85ca6cd7668e4bull, 0x3feec0f170ca07baull, 0x3c71affc2b91ce27ull, 0x3feec49182a3f090ull, 0x3c6dd235e10a73bbull, 0x3feec86319e32323ull,
+    0xbc87c50422622263ull, 0x3feecc667b5de565ull, 0x3c8b1c86e3e231d5ull, 0x3feed09bec4a2d33ull, 0xbc91bbd1d3bcbb15ull, 0x3feed503b23e255dull,
+    0x3c90cc319cee31d2ull, 0x3feed99e1330b358ull, 0x3c8469846e735ab3ull, 0x3feede6b5579fdbfull, 0xbc82dfcd978e9db4ull, 0x3feee36bbfd3f37aull,
+    0x3c8c1a7792cb3387ull, 0x3feee89f995ad3adull, 0xbc907b8f4ad1d9faull, 0x3feeee07298db666ull, 0xbc55c3d956dcaebaull, 0x3feef3a2b84f15fbull,
+    0xbc90a40e3da6f640ull, 0x3feef9728de5593aull, 0xbc68d6f438ad9334ull, 0x3feeff76f2fb5e47ull, 0xbc91eee26b588a35ull, 0x3fef05b030a1064aull,
+    0x3c74ffd70a5fddcdull, 0x3fef0c1e904bc1d2ull, 0xbc91bdfbfa9298acull, 0x3fef12c25bd71e09ull, 0x3c736eae30af0cb3ull, 0x3fef199bdd85529cull,
+    0x3c8ee3325c9ffd94ull, 0x3fef20ab5fffd07aull, 0x3c84e08fd10959acull, 0x3fef27f12e57d14bull, 0x3c63cdaf384e1a67ull, 0x3fef2f6d9406e7b5ull,
+    0x3c676b2c6c921968ull, 0x3fef3720dcef9069ull, 0xbc808a1883ccb5d2ull, 0x3fef3f0b555dc3faull, 0xbc8fad5d3ffffa6full, 0x3fef472d4a07897cull,
+    0xbc900dae3875a949ull, 0x3fef4f87080d89f2ull, 0x3c74a385a63d07a7ull, 0x3fef5818dcfba487ull, 0xbc82919e2040220full, 0x3fef60e316c98398ull,
+    0x3c8e5a50d5c192acull, 0x3fef69e603db3285ull, 0x3c843a59ac016b4bull, 0x3fef7321f301b460ull, 0xbc82d52107b43e1full, 0x3fef7c97337b9b5full,
+    0xbc892ab93b470dc9ull, 0x3fef864614f5a129ull, 0x3c74b604603a88d3ull, 0x3fef902ee78b3ff6ull, 0x3c83c5ec519d7271ull, 0x3fef9a51fbc74c83ull,
+    0xbc8ff7128fd391f0ull, 0x3fefa4afa2a490daull, 0xbc8dae98e223747dull, 0x3fefaf482d8e67f1ull, 0x3c8ec3bc41aa2008ull, 0x3fefba1bee615a27ull,
+    0x3c842b94c3a9eb32ull, 0x3fefc52b376bba97ull, 0x3c8a64a931d185eeull, 0x3fefd0765b6e4540ull, 0xbc8e37bae43be3edull, 0x3fefdbfdad9cbe14ull,
+    0x3c77893b4d91cd9dull, 0x3fefe7c1819e90d8ull, 0x3c5305c14160cc89ull, 0x3feff3c22b8f71f1ull};
+
+// glibc's __exp2f_data.tab: asuint64(2^(i/32)) - (i << 47), generated from 2^(i/32) at 80 decimal digits (glibc_expf_dev, common.h)
+__constant__ unsigned long long kGlibcExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
 // ================================================================================================ validation modes
 // dgs_params.ndt_strict_order >= 1: computeDerivatives / updateDerivatives in upstream's own operation order (SURVEY.md App. A
 // "Per point"; the CPU checker states the same sequence).  Per point: float point gradient (3x6) and second-derivative
@@ -515,7 +571,7 @@ __global__ __launch_bounds__(kBlock, PACK2 ? 2 : 4) void ndt_derivatives_kernel(
 // end in a non-finite Hessian and a failed registration.
 template <int SEARCH, bool LITERAL>
 __device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T, const NdtPair& st, const VoxelGrid& g, const double* __restrict__ vtab,
-                                                 const double gauss_d1, const float gd2, const int leaf_pow2, const bool need_h, double* out) {
+                                                 const double gauss_d1, const float gd2, const int leaf_pow2, const bool need_h, double* out, const bool exp_libm) {
 #pragma unroll
   for (int k = 0; k < kStrictAccum; k++) out[k] = 0.0;
   float xt[3];
@@ -597,7 +653,8 @@ __device__ __forceinline__ void ndt_point_strict(const float4 x, const float* T,
     float qC[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) qC[c] = q[0] * C[0][c] + q[1] * C[1][c] + q[2] * C[2][c];
-    float e_x_cov_x = det_expf(-gd2 * (q[0] * qC[0] + q[1] * qC[1] + q[2] * qC[2]) * 0.5f);
+    const float e_arg = -gd2 * (q[0] * qC[0] + q[1] * qC[1] + q[2] * qC[2]) * 0.5f;
+    float e_x_cov_x = exp_libm ? glibc_expf_dev(e_arg, kGlibcExp2fTab) : det_expf(e_arg);
     const float score_inc = (float)(-gauss_d1 * (double)e_x_cov_x);
     e_x_cov_x = gd2 * e_x_cov_x;
     if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
@@ -1055,7 +1112,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_derivatives_strict_kernel(const
                                                                         const double* __restrict__ vtab, const double gauss_d1, const float gd2,
                                                                         const int leaf_pow2, double* __restrict__ partials, double* __restrict__ rows,
                                                                         const int max_n, const int n_pairs, const int cap_blocks,
-                                                                        int* __restrict__ pair_blocks, const double gauss_d2, const size_t rows_pair_stride) {
+                                                                        int* __restrict__ pair_blocks, const double gauss_d2, const size_t rows_pair_stride, const int exp_libm) {
   int pair, slice, blocks_per_pair;
   if (!deal_workgroup(n_pairs, cap_blocks, [&](int pi) { return pairs[pi].active != 0; }, pair, slice, blocks_per_pair)) return;
   if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
@@ -1083,13 +1140,13 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_derivatives_strict_kernel(const
       xt[2] = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
       int vids[NB];
       const unsigned mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
-      strict_point_hd<SEARCH, true>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, rows + (size_t)pair * rows_pair_stride + (size_t)i * NB, row_stride);
+      strict_point_hd<SEARCH, true>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, rows + (size_t)pair * rows_pair_stride + (size_t)i * NB, row_stride, exp_libm != 0);
     }
     return;
   }
   for (int i = slice * kBlock + threadIdx.x; i < n; i += blocks_per_pair * kBlock) {
     double o[kStrictAccum];
-    ndt_point_strict<SEARCH, LITERAL>(src[i], T, st, g, vtab, gauss_d1, gd2, leaf_pow2, need_h, o);
+    ndt_point_strict<SEARCH, LITERAL>(src[i], T, st, g, vtab, gauss_d1, gd2, leaf_pow2, need_h, o, exp_libm != 0);
     if (ROWS) {
       double* __restrict__ col = rows + (size_t)pair * rows_pair_stride + i;
       for (int k = 0; k < ncol; k++) col[(size_t)k * max_n] = o[k];
@@ -1760,6 +1817,7 @@ static void fill_consts(dgs_handle* h) {
   c.strict_order = p.ndt_strict_order;
   c.newton_solver = p.ndt_newton_solver;
   c.hessian_double = (p.ndt_strict_order != DGS_NDT_ORDER_FAST && p.ndt_hessian_recompute_double) ? 1 : 0;
+  c.exp_libm = p.ndt_exp_glibc ? 1 : 0;
 }
 
 struct NdtLaunch {
@@ -1792,7 +1850,7 @@ static void launch_strict_rows(dgs_handle* h, const NdtLaunch& L, const dim3 gri
 #define DGS_LAUNCH_STRICT(LIT)                                                                                                                             \
   hipLaunchKernelGGL((ndt_derivatives_strict_kernel<SEARCH, true, LIT>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, \
                      h->vox_dbg.ptr, gd1, gd2, leaf_pow2, h->partials.ptr, h->strict_rows.ptr, L.max_n, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr,     \
-                     h->consts.gauss_d2, stride)
+                     h->consts.gauss_d2, stride, h->consts.exp_libm)
   if (literal) DGS_LAUNCH_STRICT(true); else DGS_LAUNCH_STRICT(false);
 #undef DGS_LAUNCH_STRICT
   hipLaunchKernelGGL(ndt_strict_seqsum_kernel, dim3(L.n_pairs), dim3(kWave), 0, h->stream, h->pairs.ptr, h->src_sizes.ptr, h->strict_rows.ptr, L.max_n,
@@ -1806,7 +1864,9 @@ static void launch_strict_rows(dgs_handle* h, const NdtLaunch& L, const dim3 gri
 // (Measured and dropped: the item-compacted kernel for the float kinds alone -- 64-point tiles, a third of the LDS, meant for three waves
 // per SIMD -- with the lane-per-point computeHessian kernel as the round's second launch: the register allocator spilled the double
 // accumulators, 47 ms per step.)
-static int strict_kernel_version(const dgs_handle* h) { return h->strict_kernel == 2 ? 2 : 3; }
+// (the item-compacted kernel carries ONE exponential -- glibc's, the default: with both compiled in it went from 4 to 27 spilled registers;
+//  ndt_exp_glibc = 0, the rounds 1-3 polynomial, is served by the lane-per-point kernels)
+static int strict_kernel_version(const dgs_handle* h) { return (h->strict_kernel == 2 || !h->consts.exp_libm) ? 2 : 3; }
 
 
 // item-compacted kernel, fused launches: the Newton steps of the closings go to ndt_strict_solve_kernel on the third stream

@@ -20,6 +20,59 @@
 //   * evaluation kind 2: PCL's double-precision computeHessian / updateHessian pass (dgs_params.ndt_hessian_recompute_double).
 // (no namespace of its own: included inside namespace dgs)
 
+// std::exp(double) as glibc >= 2.28 computes it on an FMA-capable x86-64 (sysdeps/ieee754/dbl-64/e_exp.c: N = 128, a 2 x 128 table of scale / tail, a
+// degree-5 polynomial, scale + scale * tmp, the -mfma build's contractions spelled out): the exponential of PCL's updateHessian.  The CPU checker
+// carries the same sequence and compares it with its libm (0 differences on 4e8 arguments).  `tab` = kGlibcExpTab.
+__device__ __forceinline__ double glibc_exp_dev(double x, const unsigned long long* __restrict__ tab) {
+#pragma clang fp contract(off)
+  constexpr double N = 128.0;
+  constexpr double kInvLn2N = 0x1.71547652b82fep0 * N, kNegLn2hiN = -0x1.62e42fefa0000p-8, kNegLn2loN = -0x1.cf79abc9e3b3ap-47, kShift = 0x1.8p52;
+  constexpr double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  const unsigned long long xb = (unsigned long long)__double_as_longlong(x);
+  const unsigned abstop = (unsigned)(xb >> 52) & 0x7ffu;
+  bool special = false;
+  if (abstop - 0x3c9u >= 0x408u - 0x3c9u) {                 // |x| < 2^-54 or |x| >= 512
+    if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;
+    if (abstop >= 0x409u) {                                 // |x| >= 1024
+      if (xb == 0xfff0000000000000ull) return 0.0;
+      if (abstop >= 0x7ffu) return 1.0 + x;
+      return (xb >> 63) ? 0.0 : __builtin_inf();
+    }
+    special = true;
+  }
+  double kd = __builtin_fma(kInvLn2N, x, kShift);
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= kShift;
+  const double r = __builtin_fma(kd, kNegLn2loN, __builtin_fma(kd, kNegLn2hiN, x));
+  const unsigned idx = 2u * (unsigned)(ki & 127ull);
+  const double tail = __longlong_as_double((long long)tab[idx]);
+  unsigned long long sbits = tab[idx + 1] + (ki << 45);
+  const double r2 = r * r;
+  double tmp = __builtin_fma(r2, __builtin_fma(r, C3, C2), tail + r);
+  tmp = __builtin_fma(r2 * r2, __builtin_fma(r, C5, C4), tmp);
+  if (special) {
+    if ((ki & 0x80000000ull) == 0) {
+      sbits -= 1009ull << 52;
+      const double scale = __longlong_as_double((long long)sbits);
+      return 0x1p1009 * __builtin_fma(scale, tmp, scale);
+    }
+    sbits += 1022ull << 52;
+    const double scale = __longlong_as_double((long long)sbits);
+    const double st = scale * tmp;
+    double y = scale + st;
+    if (y < 1.0) {
+      double lo = scale - y + st;
+      const double hi = 1.0 + y;
+      lo = 1.0 - hi + y + lo;
+      y = (hi + lo) - 1.0;
+      if (y == 0.0) y = 0.0;
+    }
+    return 0x1p-1022 * y;
+  }
+  const double scale = __longlong_as_double((long long)sbits);
+  return __builtin_fma(scale, tmp, scale);
+}
+
 // exp(double) as the CPU checker states it: the fixed sequence of det_expf without the rounding to float, the
 // scaling by 2^k split in two so that subnormal results round once.
 __device__ __forceinline__ double det_exp(double x) {
@@ -117,9 +170,10 @@ __device__ __forceinline__ StrictRecWords strict_load_rec(const VoxelStrictRec* 
   return StrictRecWords{r4[0], r4[1], r4[2], r4[3]};
 }
 
-template <bool NEED_H>
+template <bool NEED_H, bool GLIBC_ONLY = false>
 __device__ __forceinline__ bool strict_item_front(const float (&xt)[3], const float (&xj)[8], const float (&xh)[15], const StrictRecWords& w,
-                                                  const double gauss_d1, const float gd2, double (&acc)[kStrictAccum], StrictMid& m) {
+                                                  const double gauss_d1, const float gd2, double (&acc)[kStrictAccum], StrictMid& m,
+                                                  const unsigned long long* __restrict__ exptab) {
   const float pg13 = xj[0], pg23 = xj[1];
   const float pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
   const float4 ra = w.a, rb = w.b, rc = w.c, rd = w.d;
@@ -132,7 +186,8 @@ __device__ __forceinline__ bool strict_item_front(const float (&xt)[3], const fl
   float qC[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) qC[c] = q0 * m.C[0][c] + q1 * m.C[1][c] + q2 * m.C[2][c];
-  float e = det_expf(-gd2 * (q0 * qC[0] + q1 * qC[1] + q2 * qC[2]) * 0.5f);
+  const float e_arg = -gd2 * (q0 * qC[0] + q1 * qC[1] + q2 * qC[2]) * 0.5f;
+  float e = (GLIBC_ONLY || exptab) ? glibc_expf_dev(e_arg, exptab) : det_expf(e_arg);   // std::exp(float) as glibc computes it / rounds 1-3's polynomial (NdtConsts::exp_libm)
   m.score_inc = (float)(-gauss_d1 * (double)e);
   e = gd2 * e;
   if (e > 1 || e < 0 || e != e) return false;
@@ -193,12 +248,72 @@ __device__ __forceinline__ void strict_item_back(const float (&xj)[8], const Str
   acc[0] += (double)m.score_inc;
 }
 
-template <bool NEED_H>
+// One function, straight line (the front / back halves above are the same operations cut in two for the hand-pipelined A/B build).
+template <bool NEED_H, bool GLIBC_ONLY = false>
 __device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&xj)[8], const float (&xh)[15], const VoxelStrictRec* __restrict__ rec,
-                                            const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
-  StrictMid m;
-  const StrictRecWords w = strict_load_rec(rec);
-  if (strict_item_front<NEED_H>(xt, xj, xh, w, gauss_d1, gd2, acc, m)) strict_item_back<NEED_H>(xj, m, gd2, acc);
+                                            const double gauss_d1, const float gd2, double (&acc)[kStrictAccum], const unsigned long long* __restrict__ exptab) {
+  const float pg13 = xj[0], pg23 = xj[1];
+  const float pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
+  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rec);
+  const float4 ra = r4[0], rb = r4[1], rc = r4[2], rd = r4[3];
+  const double m0 = __hiloint2double(__float_as_int(ra.y), __float_as_int(ra.x)), m1 = __hiloint2double(__float_as_int(ra.w), __float_as_int(ra.z)),
+               m2 = __hiloint2double(__float_as_int(rb.y), __float_as_int(rb.x));
+  const float q0 = (float)((double)xt[0] - m0), q1 = (float)((double)xt[1] - m1), q2 = (float)((double)xt[2] - m2);
+  const float C[3][3] = {{rb.z, rb.w, rc.x}, {rc.y, rc.z, rc.w}, {rd.x, rd.y, rd.z}};
+  float qC[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) qC[c] = q0 * C[0][c] + q1 * C[1][c] + q2 * C[2][c];
+  const float e_arg = -gd2 * (q0 * qC[0] + q1 * qC[1] + q2 * qC[2]) * 0.5f;
+  float e = (GLIBC_ONLY || exptab) ? glibc_expf_dev(e_arg, exptab) : det_expf(e_arg);   // std::exp(float) as glibc computes it / rounds 1-3's polynomial
+  const float score_inc = (float)(-gauss_d1 * (double)e);
+  e = gd2 * e;
+  if (e > 1 || e < 0 || e != e) return;
+  e = (float)((double)e * gauss_d1);
+  // C * point gradient: columns 0..2 are C itself (unit columns), column 3 has a zero first factor
+  float cPG[3][3];   // columns 3, 4, 5
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    cPG[r][0] = C[r][1] * pg13 + C[r][2] * pg23;
+    cPG[r][1] = C[r][0] * pg4[0] + C[r][1] * pg4[1] + C[r][2] * pg4[2];
+    cPG[r][2] = C[r][0] * pg5[0] + C[r][1] * pg5[1] + C[r][2] * pg5[2];
+  }
+  float g6[6];
+  g6[0] = qC[0]; g6[1] = qC[1]; g6[2] = qC[2];   // q^T (C * unit column) is q^T C: the same operations
+#pragma unroll
+  for (int c = 0; c < 3; c++) g6[3 + c] = q0 * cPG[0][c] + q1 * cPG[1][c] + q2 * cPG[2][c];
+#pragma unroll
+  for (int c = 0; c < 6; c++) acc[1 + c] += (double)(e * g6[c]);
+  if (NEED_H) {
+    // x^T C H for the six distinct vectors: a = (0, xh0, xh1) b = (0, xh2, xh3) c = (0, xh4, xh5) d = xh6..8 e = xh9..11 f = xh12..14
+    float xch[6];
+    xch[0] = qC[1] * xh[0] + qC[2] * xh[1];
+    xch[1] = qC[1] * xh[2] + qC[2] * xh[3];
+    xch[2] = qC[1] * xh[4] + qC[2] * xh[5];
+    xch[3] = qC[0] * xh[6] + qC[1] * xh[7] + qC[2] * xh[8];
+    xch[4] = qC[0] * xh[9] + qC[1] * xh[10] + qC[2] * xh[11];
+    xch[5] = qC[0] * xh[12] + qC[1] * xh[13] + qC[2] * xh[14];
+    // full C * J (3 x 6) as a lookup: column i < 3 -> C[r][i], else cPG[r][i - 3]
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const float ng = -gd2 * g6[i];
+      const float cj0 = (i < 3) ? C[0][i < 3 ? i : 0] : cPG[0][i < 3 ? 0 : i - 3];
+      const float cj1 = (i < 3) ? C[1][i < 3 ? i : 0] : cPG[1][i < 3 ? 0 : i - 3];
+      const float cj2 = (i < 3) ? C[2][i < 3 ? i : 0] : cPG[2][i < 3 ? 0 : i - 3];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float t = ng * g6[j];
+        if (i >= 3 && j >= 3) {
+          const int lo = (i < j ? i : j) - 3, hi = (i < j ? j : i) - 3;
+          t = t + xch[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+        }
+        // J_j^T (C J_i): column j of J is a unit vector for j < 3 and has a zero first entry for j == 3
+        const float pcp = (j == 0) ? cj0 : (j == 1) ? cj1 : (j == 2) ? cj2 : (j == 3) ? (pg13 * cj1 + pg23 * cj2)
+                        : (j == 4) ? (pg4[0] * cj0 + pg4[1] * cj1 + pg4[2] * cj2) : (pg5[0] * cj0 + pg5[1] * cj1 + pg5[2] * cj2);
+        acc[7 + i * 6 + j] += (double)(e * (t + pcp));
+      }
+    }
+  }
+  acc[0] += (double)score_inc;
 }
 
 // the point's products with the float angle tables (computePointDerivatives).  As in the default order's kernel: rows 5..7 of the first
@@ -232,13 +347,14 @@ __device__ __forceinline__ void strict_point_tables(const float4 x, const NdtPai
 // one point, its valid voxels one after the other (a wave runs as many rounds as its fullest point has voxels)
 template <int SEARCH, bool NEED_H>
 __device__ __forceinline__ void strict_point(const float4 x, const float (&xt)[3], const int (&vids)[Offsets<SEARCH>::N], unsigned mask, const NdtPair& st,
-                                             const VoxelStrictRec* __restrict__ vs, const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
+                                             const VoxelStrictRec* __restrict__ vs, const double gauss_d1, const float gd2, double (&acc)[kStrictAccum],
+                                             const unsigned long long* __restrict__ exptab) {
   float xj[8], xh[15];
   strict_point_tables<NEED_H>(x, st, xj, xh);
   while (mask) {
     const int k = __ffs(mask) - 1;
     mask &= mask - 1u;
-    strict_item<NEED_H>(xt, xj, xh, vs + strict_pick(vids, k), gauss_d1, gd2, acc);
+    strict_item<NEED_H>(xt, xj, xh, vs + strict_pick(vids, k), gauss_d1, gd2, acc, exptab);
   }
 }
 
@@ -247,7 +363,8 @@ __device__ __forceinline__ void strict_point(const float4 x, const float (&xt)[3
 // ROWS = false: the 36 terms are added to acc[7 ..]; ROWS = true (ndt_strict_order 2): written to rows[entry * row_stride].
 template <bool ROWS>
 __device__ __forceinline__ bool strict_item_hd(const float (&xt)[3], const double (&xj)[8], const double (&xh)[15], const double* __restrict__ rec,
-                                               const double gauss_d1, const double gauss_d2, double (&acc)[kStrictAccum], double* __restrict__ rows, const size_t row_stride) {
+                                               const double gauss_d1, const double gauss_d2, double (&acc)[kStrictAccum], double* __restrict__ rows, const size_t row_stride,
+                                               const bool exp_glibc) {
   const double pg13 = xj[0], pg23 = xj[1];
   const double pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
   double q[3], C[3][3];
@@ -260,7 +377,8 @@ __device__ __forceinline__ bool strict_item_hd(const float (&xt)[3], const doubl
   double Cq[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) Cq[r] = C[r][0] * q[0] + C[r][1] * q[1] + C[r][2] * q[2];
-  double e = gauss_d2 * det_exp(-gauss_d2 * (q[0] * Cq[0] + q[1] * Cq[1] + q[2] * Cq[2]) / 2);
+  const double e_arg = -gauss_d2 * (q[0] * Cq[0] + q[1] * Cq[1] + q[2] * Cq[2]) / 2;
+  double e = gauss_d2 * (exp_glibc ? glibc_exp_dev(e_arg, kGlibcExpTab) : det_exp(e_arg));   // std::exp(double) as glibc computes it / rounds 1-3's polynomial
   if (e > 1 || e < 0 || e != e) return false;
   e *= gauss_d1;
   // x_trans . (c_inv * point_hessian block) for the six distinct vectors a = (0, xh0, xh1) b c d = xh6..8 e f
@@ -319,7 +437,7 @@ __device__ __forceinline__ void strict_point_tables_hd(const float4 xf, const Nd
 template <int SEARCH, bool ROWS>
 __device__ __forceinline__ void strict_point_hd(const float4 xf, const float (&xt)[3], const int (&vids)[Offsets<SEARCH>::N], const unsigned mask_in, const NdtPair& st,
                                                 const double* __restrict__ vtab, const double gauss_d1, const double gauss_d2, double (&acc)[kStrictAccum],
-                                                double* __restrict__ rows, const size_t row_stride) {
+                                                double* __restrict__ rows, const size_t row_stride, const bool exp_glibc) {
   constexpr int NB = Offsets<SEARCH>::N;
   double xj[8], xh[15];
   strict_point_tables_hd(xf, st, xj, xh);
@@ -328,7 +446,7 @@ __device__ __forceinline__ void strict_point_hd(const float4 xf, const float (&x
     const int k = __ffs(mask) - 1;
     mask &= mask - 1u;
     bool ok = ((mask_in >> k) & 1u) != 0;
-    if (ok) ok = strict_item_hd<ROWS>(xt, xj, xh, vtab + (size_t)strict_pick(vids, k) * 12, gauss_d1, gauss_d2, acc, ROWS ? rows + k : nullptr, row_stride);
+    if (ok) ok = strict_item_hd<ROWS>(xt, xj, xh, vtab + (size_t)strict_pick(vids, k) * 12, gauss_d1, gauss_d2, acc, ROWS ? rows + k : nullptr, row_stride, exp_glibc);
     if (ROWS && !ok) {
       for (int en = 0; en < 36; en++) rows[(size_t)en * row_stride + k] = 0.0;
     }
@@ -508,6 +626,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
   const int n = src_sizes[pair];
   const int kind = HD ? 2 : st.need_hessian;   // 0: score + gradient, 1: + Hessian (float), 2: Hessian alone in double (computeHessian)
   const float gd2 = (float)gauss_d2;
+  const unsigned long long* __restrict__ exptab = consts.exp_libm ? kGlibcExp2fTab : nullptr;
   float T[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) T[k] = st.T[k];
@@ -524,9 +643,9 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
     int vids[NB];
     const unsigned mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
     if (!mask) continue;
-    if (HD) strict_point_hd<SEARCH, false>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, nullptr, 0);
-    else if (kind == 1) strict_point<SEARCH, true>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc);
-    else strict_point<SEARCH, false>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc);
+    if (HD) strict_point_hd<SEARCH, false>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, nullptr, 0, consts.exp_libm != 0);
+    else if (kind == 1) strict_point<SEARCH, true>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc, exptab);
+    else strict_point<SEARCH, false>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc, exptab);
   }
   strict_block_row<FUSED>(acc, kind ? kStrictAccum : 7, partials + ((size_t)pair * cap_blocks + slice) * kStrictPad);
   if (!FUSED) return;
@@ -564,8 +683,9 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
 // registers into 29 in a kernel that sits at 256; the wave next door on the SIMD was hiding most of that latency already.  Not the default.
 template <bool NEED_H, int PTS>
 __device__ __forceinline__ void strict_items_float(const float* __restrict__ tf, const unsigned* __restrict__ queue, const int qn, const int lane,
-                                                   const VoxelStrictRec* __restrict__ vs, const double gauss_d1, const float gd2, double (&acc)[kStrictAccum]) {
-#if !defined(DGS_STRICT_ITEMS) || DGS_STRICT_ITEMS == 0   // the plain loop: the record loaded where it is used
+                                                   const VoxelStrictRec* __restrict__ vs, const double gauss_d1, const float gd2, double (&acc)[kStrictAccum],
+                                                   const unsigned long long* __restrict__ exptab) {
+#if !defined(DGS_STRICT_ITEMS) || DGS_STRICT_ITEMS != 1   // the plain loop: the record loaded where it is used
 #pragma unroll 1
   for (int h = 0; h < qn; h += 64) {
     const int idx = h + lane;
@@ -579,7 +699,7 @@ __device__ __forceinline__ void strict_items_float(const float* __restrict__ tf,
       for (int f = 0; f < 8; f++) xj[f] = tf[(3 + f) * PTS + slot];
 #pragma unroll
       for (int f = 0; f < 15; f++) xh[f] = NEED_H ? tf[(11 + f) * PTS + slot] : 0.f;
-      strict_item<NEED_H>(xt, xj, xh, vs + (entry & 0x1FFFFFFu), gauss_d1, gd2, acc);
+      strict_item<NEED_H, true>(xt, xj, xh, vs + (entry & 0x1FFFFFFu), gauss_d1, gd2, acc, exptab);
     }
   }
 #else
@@ -608,7 +728,7 @@ __device__ __forceinline__ void strict_items_float(const float* __restrict__ tf,
 #pragma unroll
         for (int f = 0; f < 15; f++) xh[f] = 0.f;
       }
-      alive = strict_item_front<NEED_H>(xt, xj, xh, w, gauss_d1, gd2, acc, m);
+      alive = strict_item_front<NEED_H, true>(xt, xj, xh, w, gauss_d1, gd2, acc, m, exptab);
     }
     StrictRecWords wn = w;
     if (have_n) wn = strict_load_rec(vs + (entry_n & 0x1FFFFFFu));
@@ -676,6 +796,11 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
 
   __shared__ __attribute__((aligned(16))) unsigned char s_tab[kBlock / kWave][TL::kTableBytes];
   __shared__ unsigned s_queue[kBlock / kWave][TL::kQueue];
+  // glibc's 2^(i/32) table in LDS: the item loop looks it up per lane (an LDS read instead of a gather through the vector cache)
+  __shared__ unsigned long long s_exp2f[32];
+  if (threadIdx.x < 32) s_exp2f[threadIdx.x] = kGlibcExp2fTab[threadIdx.x];
+  __syncthreads();
+  const unsigned long long* __restrict__ exptab = s_exp2f;   // this kernel serves consts.exp_libm = 1 only (strict_kernel_version, ndt_align.hip)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* tf = reinterpret_cast<float*>(s_tab[wave]);            // float kinds: [26][PTS]
   double* td = reinterpret_cast<double*>(s_tab[wave]);          // double pass: [23][PTS_HD] doubles, then [3][PTS_HD] floats
@@ -762,14 +887,26 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
-    // ---- the items, 64 at a time
-    if (WITH_HD && kind == 2) {
+    // ---- the items, 64 at a time.  The float kinds run strict_items_float, a loop specialised per kind (the default, DGS_STRICT_ITEMS = 2); the
+    // loop below serves the double pass -- and, in the A/B build DGS_STRICT_ITEMS = 0, all three kinds with the kind tested per round: that form
+    // has 7 spilled registers instead of 25 and is 1 % SLOWER on the bench step (5.35 against 5.27-5.30 ms, same box, two runs each).
+#ifndef DGS_STRICT_ITEMS
+#define DGS_STRICT_ITEMS 2
+#endif
+#if DGS_STRICT_ITEMS != 0
+    if (!(WITH_HD && kind == 2)) {
+      if (kind == 1) strict_items_float<true, TL::PTS>(tf, queue, qn, lane, vs, gauss_d1, gd2, acc, exptab);
+      else strict_items_float<false, TL::PTS>(tf, queue, qn, lane, vs, gauss_d1, gd2, acc, exptab);
+      qn = 0;
+    }
+#endif
 #pragma unroll 1
-      for (int h = 0; h < qn; h += 64) {
-        const int idx = h + lane;
-        if (idx < qn) {
-          const unsigned entry = queue[idx];
-          const int slot = (int)(entry >> 25), vid = (int)(entry & 0x1FFFFFFu);
+    for (int h = 0; h < qn; h += 64) {
+      const int idx = h + lane;
+      if (idx < qn) {
+        const unsigned entry = queue[idx];
+        const int slot = (int)(entry >> 25), vid = (int)(entry & 0x1FFFFFFu);
+        if (WITH_HD && kind == 2) {
           double xj[8], xh[15];
           float xt[3];
 #pragma unroll
@@ -778,13 +915,24 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
           for (int f = 0; f < 15; f++) xh[f] = td[(8 + f) * TL::PTS_HD + slot];
 #pragma unroll
           for (int f = 0; f < 3; f++) xt[f] = tdx[f * TL::PTS_HD + slot];
-          (void)strict_item_hd<false>(xt, xj, xh, vtab + (size_t)vid * 12, gauss_d1, gauss_d2, acc, nullptr, 0);
+          (void)strict_item_hd<false>(xt, xj, xh, vtab + (size_t)vid * 12, gauss_d1, gauss_d2, acc, nullptr, 0, true);
+        } else {
+          float xt[3], xj[8], xh[15];
+#pragma unroll
+          for (int f = 0; f < 3; f++) xt[f] = tf[f * TL::PTS + slot];
+#pragma unroll
+          for (int f = 0; f < 8; f++) xj[f] = tf[(3 + f) * TL::PTS + slot];
+          if (kind == 1) {
+#pragma unroll
+            for (int f = 0; f < 15; f++) xh[f] = tf[(11 + f) * TL::PTS + slot];
+            strict_item<true, true>(xt, xj, xh, vs + vid, gauss_d1, gd2, acc, exptab);
+          } else {
+#pragma unroll
+            for (int f = 0; f < 15; f++) xh[f] = 0.f;
+            strict_item<false, true>(xt, xj, xh, vs + vid, gauss_d1, gd2, acc, exptab);
+          }
         }
       }
-    } else if (kind == 1) {
-      strict_items_float<true, TL::PTS>(tf, queue, qn, lane, vs, gauss_d1, gd2, acc);
-    } else {
-      strict_items_float<false, TL::PTS>(tf, queue, qn, lane, vs, gauss_d1, gd2, acc);
     }
     __builtin_amdgcn_wave_barrier();   // the next tile overwrites the tables and the queue (LDS operations of one wave stay in order)
   }

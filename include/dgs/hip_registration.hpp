@@ -68,11 +68,12 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
   // dgs_ndt_strict_order: 0 fast (re-associated, opt-in), 1 upstream operation order (default), 2 + index-order sums (validation, dgs_reg.h)
   void setNdtStrictOrder(int order) { params_.ndt_strict_order = order; dirty_ = true; }
   // the pieces of the upstream order, one by one (all on by default; dgs_reg.h): Eigen's two-sided JacobiSVD sequence for the Newton
-  // step, PCL's double computeHessian after a line search, the guess's rotation as Affine3f::rotation() takes it
-  void setNdtUpstreamFidelity(bool jacobi_svd, bool hessian_double, bool guess_polar) {
+  // step, PCL's double computeHessian after a line search, the guess's rotation as Affine3f::rotation() takes it, std::exp(float) as glibc computes it
+  void setNdtUpstreamFidelity(bool jacobi_svd, bool hessian_double, bool guess_polar, bool exp_glibc = true) {
     params_.ndt_newton_solver = jacobi_svd;
     params_.ndt_hessian_recompute_double = hessian_double;
     params_.ndt_guess_rotation_polar = guess_polar;
+    params_.ndt_exp_glibc = exp_glibc;
     dirty_ = true;
   }
   void setOulierRatio(double r) { params_.ndt_outlier_ratio = r; dirty_ = true; }  // (sic) upstream spelling

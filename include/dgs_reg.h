@@ -119,7 +119,7 @@ typedef struct dgs_params {
   /* FAST_VGICP (uses the gicp_* fields above except gicp_max_correspondence_distance: VGICP has no distance gate) */
   int32_t vgicp_search_method;             /* default DGS_VGICP_DIRECT1 (FastVGICP constructor) */
   double vgicp_resolution;                 /* setResolution(reg_resolution), factory default 1.0 (registrations.cpp:52) */
-  /* ---- three details of un-vendored upstream code behind named switches (ABI 5; [UPSTREAM-RECALL]).  Each
+  /* ---- four details of un-vendored upstream code behind named switches (ABI 5; [UPSTREAM-RECALL]).  Each
    * defaults to what the published upstream source does as far as it can be recalled; 0 restores the stand-in of ABI <= 4. ---- */
   int32_t ndt_newton_solver;            /* upstream evaluation orders (ndt_strict_order >= 1): 1 = Eigen::JacobiSVD's own two-sided Jacobi sequence
                                            (what computeTransformation's `sv.solve(-score_gradient)` runs); 0 = one-sided Hestenes Jacobi.  The FAST
@@ -129,7 +129,11 @@ typedef struct dgs_params {
                                            orders only (the FAST order re-runs its own float pass). */
   int32_t ndt_guess_rotation_polar;     /* initial pose vector: Euler angles of Affine3f::rotation(), i.e. of the polar factor of the guess's 3x3
                                            (a float JacobiSVD) = 1, of the raw 3x3 = 0.  All orders. */
-  int32_t reserved0;
+  int32_t ndt_exp_glibc;                /* upstream evaluation orders: updateDerivatives' `std::exp(float)`: 1 = glibc's expf (>= 2.27, the x86-64 FMA build)
+                                           restated operation for operation -- the restatement is compared with the build image's libm on every
+                                           float in [-104, 0] (tests/test_oracle_round4.py); 0 = the platform-independent polynomial of ABI <= 4
+                                           (correctly rounded but for ~1e-9 of the arguments: NOT what a libm returns).  The FAST order uses the
+                                           device library's expf either way.  (Was reserved0: same struct size.) */
 } dgs_params;
 
 /* What the callers read back after align(): hasConverged(), getFinalTransformation(), and the

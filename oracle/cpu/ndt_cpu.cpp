@@ -288,7 +288,7 @@ double NdtCpu::derivatives_with(const float* T, const double p[6], double g[6], 
       float qC[3];
       for (int c = 0; c < 3; c++) qC[c] = q[0] * C[0][c] + q[1] * C[1][c] + q[2] * C[2][c];
       const float e_arg = -gd2 * (q[0] * qC[0] + q[1] * qC[1] + q[2] * qC[2]) * 0.5f;
-      float e_x_cov_x = prm.exp_libm ? std::exp(e_arg) : det_expf(e_arg);
+      float e_x_cov_x = prm.exp_libm == 1 ? glibc_expf(e_arg) : (prm.exp_libm == 2 ? std::exp(e_arg) : det_expf(e_arg));
       const float score_inc = static_cast<float>(-gauss_d1 * e_x_cov_x);
       e_x_cov_x = gd2 * e_x_cov_x;
       if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
@@ -395,7 +395,8 @@ void NdtCpu::hessian_double_with(const float* T, double H[36]) {
           };
           double Cq[3];
           Cmul(q, Cq);
-          double e_x_cov_x = gauss_d2 * det_exp(-gauss_d2 * dot3(q, Cq) / 2);
+          const double e_arg = -gauss_d2 * dot3(q, Cq) / 2;
+          double e_x_cov_x = gauss_d2 * (prm.exp_libm == 1 ? glibc_exp(e_arg) : (prm.exp_libm == 2 ? std::exp(e_arg) : det_exp(e_arg)));
           if (e_x_cov_x > 1 || e_x_cov_x < 0 || e_x_cov_x != e_x_cov_x) continue;
           e_x_cov_x *= gauss_d1;
           double* out = terms.data() + (static_cast<size_t>(li) * 27 + cnt) * 36;

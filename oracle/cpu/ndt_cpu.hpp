@@ -33,7 +33,7 @@ struct NdtParams {
   int mt_max_step_iterations = 10;
   int fix_hessian_d1 = 0;                // 0 = upstream table (h_ang_d1 z-term +sy), 1 = exact second derivative (-sy)
   int num_threads = 0;                   // registrations.cpp:102,106-108 (0 = all cores)
-  int exp_libm = 0;                      // 0 = det_expf (linalg.hpp: platform-independent value of std::exp(float)), 1 = the host libm's expf
+  int exp_libm = 1;                      // std::exp(float) of updateDerivatives: 1 = glibc's expf restated (linalg.hpp glibc_expf: equal to the image's libm on every float in [-104, 0]), 0 = det_expf (rounds 1-3's stand-in), 2 = the host libm's expf itself
   // ---- round 4: three upstream details that rounds 1-3 replaced by stand-ins (all [UPSTREAM-RECALL]) ----
   int newton_solver = 1;                 // 1 = Eigen::JacobiSVD's own two-sided Jacobi sequence (linalg.hpp jsvd_solve6); 0 = one-sided Hestenes Jacobi (rounds 1-3)
   int hessian_recompute_double = 1;      // computeStepLengthMT's closing computeHessian: 1 = PCL's double-precision computeHessian / updateHessian

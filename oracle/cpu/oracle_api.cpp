@@ -130,6 +130,64 @@ void orc_ndt_hessian_double(void* h, const double* p6, double* H36) {
   n->hessian_double(p6, H36);
 }
 double orc_det_exp(double x) { return det_exp(x); }
+float orc_glibc_expf(float x) { return glibc_expf(x); }
+double orc_glibc_exp(double x) { return glibc_exp(x); }
+// glibc_exp against the host libm's exp on n doubles drawn by a fixed xorshift stream over [-760, 720] (an eighth each positives up to overflow,
+// negatives through the subnormal results to underflow and tiny magnitudes; the rest dense in [-60, 0], NDT's range): the number that differ
+long long orc_glibc_exp_mismatches(long long n, uint64_t seed, double* first_bad) {
+  long long bad = 0;
+  double fb = 0.0;
+#pragma omp parallel reduction(+ : bad)
+  {
+    uint64_t s = seed + 977ull * (uint64_t)omp_get_thread_num() + 1ull;
+    const int nt = omp_get_num_threads();
+    const long long mine = n / nt + 1;
+    for (long long i = 0; i < mine; i++) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      const double u = (double)(s >> 11) / 9007199254740992.0;
+      double x;
+      switch (s & 7) {
+        case 0: x = 720.0 * u; break;
+        case 1: x = -760.0 * u; break;
+        case 2: { const uint64_t b = 0x3ff0000000000000ull - (((s >> 20) % 60ull) << 52); double t; std::memcpy(&t, &b, 8); x = -t * u; } break;
+        default: x = -60.0 * u * u; break;
+      }
+      const double a = exp(x), m = glibc_exp(x);
+      uint64_t ua, um;
+      std::memcpy(&ua, &a, 8);
+      std::memcpy(&um, &m, 8);
+      if (ua != um && !(a != a && m != m)) {
+        bad++;
+#pragma omp critical
+        fb = x;
+      }
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return bad;
+}
+// glibc_expf against the host libm's expf on every float whose bit pattern lies in [first_bits, last_bits] (both ends included): the
+// number of floats whose results differ in any bit; *first_bad receives the bit pattern of the first one (or 0xFFFFFFFF)
+long long orc_glibc_expf_mismatches(uint32_t first_bits, uint32_t last_bits, uint32_t* first_bad) {
+  long long bad = 0;
+  uint32_t fb = 0xFFFFFFFFu;
+#pragma omp parallel for reduction(+ : bad) reduction(min : fb) schedule(static)
+  for (long long b = (long long)first_bits; b <= (long long)last_bits; b++) {
+    const uint32_t u = (uint32_t)b;
+    float x;
+    std::memcpy(&x, &u, 4);
+    const float a = expf(x), m = glibc_expf(x);
+    uint32_t ua, um;
+    std::memcpy(&ua, &a, 4);
+    std::memcpy(&um, &m, 4);
+    if (ua != um && !(a != a && m != m)) {
+      bad++;
+      if (u < fb) fb = u;
+    }
+  }
+  if (first_bad) *first_bad = fb;
+  return bad;
+}
 void orc_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); }
 void orc_sym_eig3(const double* A, double* ev, double* V) { sym_eig3(A, ev, V); }
 int32_t orc_max_threads(void) {

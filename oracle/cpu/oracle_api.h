@@ -37,6 +37,10 @@ void orc_jsvd_solve6(const double* A36, const double* b6, double* x6, int32_t* s
 void orc_affine_rotation_f32(const float* T16, float* R9_rowmajor);
 void orc_ndt_hessian_double(void* h, const double* p6, double* H36);
 double orc_det_exp(double x);
+double orc_glibc_exp(double x);   /* linalg.hpp glibc_exp: std::exp(double) as glibc >= 2.28 computes it (FMA build) */
+long long orc_glibc_exp_mismatches(long long n, uint64_t seed, double* first_bad);
+float orc_glibc_expf(float x);   /* linalg.hpp glibc_expf: std::exp(float) as glibc >= 2.27 computes it on an FMA-capable x86-64 */
+long long orc_glibc_expf_mismatches(uint32_t first_bits, uint32_t last_bits, uint32_t* first_bad);   /* ... against the host libm, float by float */
 void orc_ldlt_solve6(const double* A36, const double* b6, double* x6);
 void orc_sym_eig3(const double* A9, double* evals3, double* V9);
 int32_t orc_max_threads(void);

@@ -104,7 +104,7 @@ class NdtOracle:
 
     def __init__(self, resolution=1.0, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
                  step_size=0.1, outlier_ratio=0.55, line_search=1, num_threads=0, min_points_per_voxel=6,
-                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False, exp_libm=0,
+                 min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False, exp_libm=1,
                  newton_solver=1, hessian_recompute_double=1, guess_rotation_polar=1):
         L = lib(perturbed)
         self._L = L
@@ -122,7 +122,7 @@ class NdtOracle:
         p.min_covar_eigvalue_mult = min_covar_eigvalue_mult
         p.mt_max_step_iterations = mt_max_step_iterations
         p.fix_hessian_d1 = fix_hessian_d1
-        p.exp_libm = exp_libm   # 1: the host libm's expf instead of the platform-independent det_expf (a <= 1 ulp perturbation)
+        p.exp_libm = exp_libm   # std::exp(float): 1 = glibc's expf restated (equal to the image's libm on every float in [-104, 0]), 0 = det_expf (rounds 1-3), 2 = the host libm itself
         # round 4 (ndt_cpu.hpp): Eigen's two-sided JacobiSVD sequence / PCL's double computeHessian / Affine3f::rotation() -- 0 = rounds 1-3
         p.newton_solver = newton_solver
         p.hessian_recompute_double = hessian_recompute_double
@@ -245,6 +245,45 @@ def det_exp(x: float) -> float:
     L.orc_det_exp.restype = C.c_double
     L.orc_det_exp.argtypes = [C.c_double]
     return float(L.orc_det_exp(float(x)))
+
+
+def glibc_expf(x) -> float:
+    """linalg.hpp glibc_expf: std::exp(float) as glibc computes it (the restatement's default for updateDerivatives' exponential)."""
+    L = lib()
+    L.orc_glibc_expf.restype = C.c_float
+    L.orc_glibc_expf.argtypes = [C.c_float]
+    return float(L.orc_glibc_expf(float(np.float32(x))))
+
+
+def glibc_exp(x: float) -> float:
+    """linalg.hpp glibc_exp: std::exp(double) as glibc computes it (the double computeHessian pass's exponential)."""
+    L = lib()
+    L.orc_glibc_exp.restype = C.c_double
+    L.orc_glibc_exp.argtypes = [C.c_double]
+    return float(L.orc_glibc_exp(float(x)))
+
+
+def glibc_exp_mismatches(n: int, seed: int = 88172645463325252):
+    """glibc_exp against the host libm's exp on ~n doubles of a fixed pseudo-random stream over [-760, 720]; (count, one differing argument)."""
+    L = lib()
+    L.orc_glibc_exp_mismatches.restype = C.c_longlong
+    L.orc_glibc_exp_mismatches.argtypes = [C.c_longlong, C.c_uint64, C.POINTER(C.c_double)]
+    fb = C.c_double(0)
+    m = int(L.orc_glibc_exp_mismatches(int(n), int(seed), C.byref(fb)))
+    return m, (None if m == 0 else fb.value)
+
+
+def glibc_expf_mismatches(first: float, last: float):
+    """Floats between `first` and `last` (same sign, |first| <= |last|: bit patterns ascending) on which glibc_expf and the host libm's
+    expf differ; returns (count, first differing float or None)."""
+    L = lib()
+    L.orc_glibc_expf_mismatches.restype = C.c_longlong
+    L.orc_glibc_expf_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    a = int(np.float32(first).view(np.uint32))
+    b = int(np.float32(last).view(np.uint32))
+    fb = C.c_uint32(0)
+    n = int(L.orc_glibc_expf_mismatches(a, b, C.byref(fb)))
+    return n, (None if n == 0 else float(np.uint32(fb.value).view(np.float32)))
 
 
 def ldlt_solve6(A, b):
@@ -440,15 +479,17 @@ def _ulp_shift(G, k):
 
 def ndt_band(tgt, src, guess=None, twins=None, **kw):
     """The restated algorithm's own reproducibility on one pair: the largest deviation of its answer under perturbations that
-    carry no information -- the same source compiled with FMA contraction, the host libm's expf instead of the platform-independent
-    one, and the float32 initial guess moved by +-1 and +-2 ulps.  `twins` selects a subset (tuples (perturbed build, exp_libm,
-    ulps)).  Returns (result of the unperturbed run, band_translation [m], band_rotation [rad])."""
+    carry no information -- the same source compiled with FMA contraction, the OTHER exp(float) (det_expf where the run uses glibc's
+    expf and the other way round: a <= 1 ulp perturbation), and the float32 initial guess moved by +-1 and +-2 ulps.  `twins` selects a
+    subset (tuples (perturbed build, other exp, ulps)).  Returns (result of the unperturbed run, band_translation [m], band_rotation [rad])."""
     G = np.eye(4, dtype=np.float32) if guess is None else np.asarray(guess, np.float32)
     if twins is None:
         twins = ((True, 0, 0), (False, 1, 0), (False, 0, 1), (False, 0, -1), (False, 0, 2), (False, 0, -2))
+    kw = dict(kw)
+    base_exp = int(kw.pop("exp_libm", 1))
     runs = []
-    for perturbed, libm, k in ((False, 0, 0),) + tuple(twins):
-        o = NdtOracle(perturbed=perturbed, exp_libm=libm, **kw)
+    for perturbed, other_exp, k in ((False, 0, 0),) + tuple(twins):
+        o = NdtOracle(perturbed=perturbed, exp_libm=(0 if base_exp else 1) if other_exp else base_exp, **kw)
         o.set_target(tgt)
         o.set_source(src)
         runs.append(o.align(_ulp_shift(G, k)))

@@ -111,3 +111,34 @@ def test_each_switch_changes_the_run_it_governs_and_only_by_rounding():
     # the polar factor moves the initial pose vector by float rounding of the rotation block, the others leave it alone
     assert np.array_equal(runs["newton_solver"]["trajectory"][0], runs["none"]["trajectory"][0])
     assert np.abs(runs["guess_rotation_polar"]["trajectory"][0] - runs["none"]["trajectory"][0]).max() <= 1e-6
+
+
+def test_glibc_expf_restatement_equals_the_images_libm_on_every_float_ndt_can_pass():
+    """PINNED component: upstream's updateDerivatives calls std::exp(float).  linalg.hpp glibc_expf restates glibc's algorithm (>= 2.27, the
+    x86-64 FMA build); here it is compared with the expf of THIS image's libm on every float in [-104, 0] -- NDT's exponent is -d2 q^T C q / 2,
+    never positive; below -103.97 both return 0 -- 1.1e9 arguments, bit for bit.  (Measured once over [-104, 88] as well: 0 of 2.24e9 differ;
+    the unfused form of the range reduction differs on 2.)  The device library carries the same operation sequence (csrc/common.h)."""
+    n, first = orc.glibc_expf_mismatches(-0.0, -104.0)
+    assert (n, first) == (0, None)
+    n, first = orc.glibc_expf_mismatches(0.0, 1.0)          # and a slice of the positive side
+    assert (n, first) == (0, None)
+    for x in (-1.0, -0.5, -10.0, -87.5, -100.0, -103.9):
+        assert orc.glibc_expf(x) == float(np.exp(np.float32(x), dtype=np.float32)) or abs(orc.glibc_expf(x) - math.exp(x)) <= 1.2e-7 * math.exp(x)
+    assert orc.glibc_expf(-104.0) == 0.0 and orc.glibc_expf(float("-inf")) == 0.0 and math.isnan(orc.glibc_expf(float("nan")))
+
+
+def test_exp_switch_selects_glibc_or_the_rounds_1_to_3_polynomial():
+    """NdtParams::exp_libm: 1 (default) = glibc_expf, 2 = the host libm itself (the same bits, by the test above), 0 = det_expf.  The three
+    agree to one float ulp per exponential, so an evaluation moves by ~1e-8 relative between 0 and 1 and not at all between 1 and 2."""
+    tgt, src, _ = synth.planar_pair(n=8192)
+    p = np.array([0.2, -0.05, 0.03, 0.02, -0.03, 0.04])
+    out = {}
+    for mode in (0, 1, 2):
+        o = orc.NdtOracle(resolution=1.0, exp_libm=mode)
+        o.set_target(tgt)
+        o.set_source(src)
+        out[mode] = o.derivatives(p)
+    assert orc.NdtOracle(resolution=1.0).params.exp_libm == 1
+    assert out[1][0] == out[2][0] and np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][2], out[2][2])
+    assert out[0][0] != out[1][0] and abs(out[0][0] - out[1][0]) <= 1e-7 * abs(out[1][0])
+    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-6 * np.abs(out[1][2]).max()

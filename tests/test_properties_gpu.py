@@ -276,12 +276,14 @@ def test_fused_launches_equal_launch_pairs_bit_for_bit(scans, order):
     for _ in range(4):
         got = a.align_batch(src, gs)
         for c, (x, y) in enumerate(zip(got, ref)):
-            assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"] and x["evaluations"] == y["evaluations"], c
+            assert np.array_equal(x["T"], y["T"]) and x["iterations"] == y["iterations"], c
             assert x["fitness"] == y["fitness"]
             if order == 0:
-                assert x["score"] == y["score"], c
+                assert x["score"] == y["score"] and x["evaluations"] == y["evaluations"], c
             else:   # upstream order: the unfused launch deals its workgroups over the pairs still active, the fused one by NdtPair::serve --
-                #     another (fixed) partition of the double sums per launch structure: the last bits of a score may differ, the floats of T not
+                #     another (fixed) partition of the double sums per launch structure: the last bits of a score may differ, the floats of T
+                #     not; and a More-Thuente search that sits on its clamped minimum step decides its sufficient-decrease test at that 1e-14
+                #     level, so it may take another number of trials (they refine the step by < 1e-9: same iterate, same transform) -- DESIGN 2a
                 assert abs(x["score"] - y["score"]) <= 1e-13 * abs(y["score"]), c
         if order == 0:
             assert np.array_equal(a.ndt_trajectory(5), b.ndt_trajectory(5))
