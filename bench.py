@@ -88,6 +88,22 @@ def parse_args(argv=None):
     return args
 
 
+_LINE_FD = None
+
+
+def claim_stdout():
+    global _LINE_FD
+    if _LINE_FD is None:
+        sys.stdout.flush()
+        _LINE_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(line: str):
+    sys.stdout.flush()
+    os.write(_LINE_FD if _LINE_FD is not None else 1, (line + "\n").encode())
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_child:
@@ -97,6 +113,10 @@ def main():
     # initialised HIP must never be replaced or forked), as a child `torch.distributed.run`, and leave with its status.
     if args.gpus > 1 and not args.group and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+
+    # From here on file descriptor 1 belongs to the ONE JSON line: libraries write to it too (RCCL prints its version banner there on some
+    # boxes), so everything else -- Python's prints and C's alike -- is sent to stderr and the line goes out through the saved descriptor.
+    claim_stdout()
 
     import torch
     import torch.distributed as dist
@@ -364,7 +384,7 @@ def main():
                 out["roofline"]["traffic"], out["roofline"]["traffic_detail"] = measure_traffic(args, bytes_per_eval, "ndt_strict3_kernel" if args.order == 1 else "ndt_derivatives_kernel")
             except Exception as e:  # profiler missing / refused: the counter stays null, the bench line is still valid
                 out["roofline"]["traffic_detail"] = {"error": repr(e)[:200]}
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -613,12 +633,12 @@ def dry_run(args, rank, world, backend):
     if args.group:
         G = args.gpus
         shares = [len(range(k, G * P, G)) for k in range(G)]
-        print(json.dumps({"metric": METRIC, "value": None, "unit": "registrations/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+        emit_line(json.dumps({"metric": METRIC, "value": None, "unit": "registrations/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                           "dry_run": True,
                           "config": {"workload": "dry run: single-process group shape only", "pairs_per_gpu": P, "group": True, "members": G,
                                      "candidates_per_step": G * P, "shares": shares, "processes": 1,
-                                     "collective_backend": "rccl (ncclCommInitAll)", "collective_world_size": G}}), flush=True)
+                                     "collective_backend": "rccl (ncclCommInitAll)", "collective_world_size": G}}))
         return
     if backend == "nccl" and not torch.cuda.is_available():
         backend = "gloo"
@@ -647,12 +667,12 @@ def dry_run(args, rank, world, backend):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": None, "unit": "registrations/s", "n_gpus": world,
+        emit_line(json.dumps({"metric": METRIC, "value": None, "unit": "registrations/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic", "dry_run": True,
                           "config": {"workload": "dry run: launcher + collective plumbing only", "pairs_per_gpu": P,
                                      "collective_backend": (dist.get_backend() if world > 1 else None), "collective_world_size": world,
-                                     "ranks_seen_in_all_gather": seen}}), flush=True)
+                                     "ranks_seen_in_all_gather": seen}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

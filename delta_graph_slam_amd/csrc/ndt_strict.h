@@ -264,7 +264,12 @@ __device__ __forceinline__ void strict_item(const float (&xt)[3], const float (&
 #pragma unroll
   for (int c = 0; c < 3; c++) qC[c] = q0 * C[0][c] + q1 * C[1][c] + q2 * C[2][c];
   const float e_arg = -gd2 * (q0 * qC[0] + q1 * qC[1] + q2 * qC[2]) * 0.5f;
+#ifdef DGS_AB_DETF   // timing A/B only (`make ab AB=-DDGS_AB_DETF`): the rounds 1-3 polynomial in the item-compacted kernel -- 5.39-5.41 ms per bench step
+                     // against 5.38 with glibc's expf (same box, two runs each): the exact libm exponential costs nothing
+  float e = det_expf(e_arg);
+#else
   float e = (GLIBC_ONLY || exptab) ? glibc_expf_dev(e_arg, exptab) : det_expf(e_arg);   // std::exp(float) as glibc computes it / rounds 1-3's polynomial
+#endif
   const float score_inc = (float)(-gauss_d1 * (double)e);
   e = gd2 * e;
   if (e > 1 || e < 0 || e != e) return;

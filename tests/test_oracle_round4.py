@@ -142,3 +142,17 @@ def test_exp_switch_selects_glibc_or_the_rounds_1_to_3_polynomial():
     assert out[1][0] == out[2][0] and np.array_equal(out[1][1], out[2][1]) and np.array_equal(out[1][2], out[2][2])
     assert out[0][0] != out[1][0] and abs(out[0][0] - out[1][0]) <= 1e-7 * abs(out[1][0])
     assert np.abs(out[0][2] - out[1][2]).max() <= 1e-6 * np.abs(out[1][2]).max()
+
+
+def test_glibc_exp_restatement_equals_the_images_libm_on_a_fixed_stream_of_doubles():
+    """PCL's updateHessian calls std::exp(double).  linalg.hpp glibc_exp restates glibc's algorithm (>= 2.28, the -mfma build: which products are
+    fused was settled against this libm) with its special cases; here against the image's exp on 2e8 doubles of a fixed xorshift stream -- an
+    eighth each positives up to overflow, negatives through the subnormal results to underflow and tiny magnitudes, the rest dense in [-60, 0]
+    where NDT's exponent lives.  A statistical pin (the domain cannot be walked), bit for bit."""
+    n, bad = orc.glibc_exp_mismatches(200_000_000)
+    assert (n, bad) == (0, None)
+    n, bad = orc.glibc_exp_mismatches(20_000_000, seed=2463534242)
+    assert (n, bad) == (0, None)
+    for x in (-1.0, -0.5, -30.0, -600.0, -740.0, 0.0, 1e-300, 5.0, 709.0):
+        assert orc.glibc_exp(x) == math.exp(x), x
+    assert orc.glibc_exp(-800.0) == 0.0 and math.isinf(orc.glibc_exp(800.0)) and math.isnan(orc.glibc_exp(float("nan")))
