@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __
                                                                 int* __restrict__ scalars, int min_points, double eig_mult,
                                                                 int* __restrict__ cell2vox, VoxelRec* __restrict__ vox,
                                                                 float4* __restrict__ centroid, double* __restrict__ dbg,
-                                                                int* __restrict__ vcount, int* __restrict__ vvalid, VoxelStrictRec* __restrict__ vstrict) {
+                                                                int* __restrict__ vcount, int* __restrict__ vvalid, VoxelStrictRec* __restrict__ vstrict, const int eigen_qr) {
 #pragma clang fp contract(off)  // the table is compared bit for bit with the CPU checker: every operation individually rounded
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int num_runs = scalars[0];
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(kBlock) void voxel_finalize_kernel(const float4* __
     for (int a = 0; a < 3; a++)
       for (int b = 0; b < 3; b++) cov[a * 3 + b] = ((sq[a * 3 + b] - 2.0 * (s[a] * mean[b])) / np + mean[a] * mean[b]) * f;
     double ev[3], V[9];
-    sym_eig3_d(cov, ev, V);
+    if (eigen_qr) eigen_selfadjoint3_d(cov, ev, V);   // Eigen's SelfAdjointEigenSolver sequence (dgs_params.ndt_cov_eigensolver = 1, default)
+    else sym_eig3_d(cov, ev, V);                       // cyclic Jacobi (rounds 1-3)
     if (!(ev[0] < 0 || ev[1] < 0 || ev[2] <= 0)) {
       const double min_ev = eig_mult * ev[2];
       if (ev[0] < min_ev) {
@@ -526,7 +527,8 @@ int ndt_build_target(dgs_handle* h) {
   // 5. per-voxel statistics
   hipLaunchKernelGGL(voxel_finalize_kernel, dim3(nb), dim3(kBlock), 0, st, h->scratch_cloud.ptr, h->run_keys.ptr, h->run_counts.ptr,
                      h->run_offsets.ptr, h->dev_scalars.ptr, h->prm.ndt_min_points_per_voxel, h->prm.ndt_min_covar_eigvalue_mult,
-                     h->cell2vox.ptr, h->vox.ptr, h->vox_centroid.ptr, h->vox_dbg.ptr, h->vox_count.ptr, h->vox_valid.ptr, h->vox_strict.ptr);
+                     h->cell2vox.ptr, h->vox.ptr, h->vox_centroid.ptr, h->vox_dbg.ptr, h->vox_count.ptr, h->vox_valid.ptr, h->vox_strict.ptr,
+                     h->prm.ndt_cov_eigensolver);
   prof_end(h, DGS_K_NDT_VOXEL_BUILD, slot);
   DGS_HIP_TRY(h, hipGetLastError());
   g.cell2vox = h->cell2vox.ptr;

@@ -69,11 +69,12 @@ class HipRegistration : public pcl::Registration<PointSource, PointTarget, float
   void setNdtStrictOrder(int order) { params_.ndt_strict_order = order; dirty_ = true; }
   // the pieces of the upstream order, one by one (all on by default; dgs_reg.h): Eigen's two-sided JacobiSVD sequence for the Newton
   // step, PCL's double computeHessian after a line search, the guess's rotation as Affine3f::rotation() takes it, std::exp(float) as glibc computes it
-  void setNdtUpstreamFidelity(bool jacobi_svd, bool hessian_double, bool guess_polar, bool exp_glibc = true) {
+  void setNdtUpstreamFidelity(bool jacobi_svd, bool hessian_double, bool guess_polar, bool exp_glibc = true, bool cov_eigen_qr = true) {
     params_.ndt_newton_solver = jacobi_svd;
     params_.ndt_hessian_recompute_double = hessian_double;
     params_.ndt_guess_rotation_polar = guess_polar;
     params_.ndt_exp_glibc = exp_glibc;
+    params_.ndt_cov_eigensolver = cov_eigen_qr;
     dirty_ = true;
   }
   void setOulierRatio(double r) { params_.ndt_outlier_ratio = r; dirty_ = true; }  // (sic) upstream spelling

@@ -119,7 +119,7 @@ typedef struct dgs_params {
   /* FAST_VGICP (uses the gicp_* fields above except gicp_max_correspondence_distance: VGICP has no distance gate) */
   int32_t vgicp_search_method;             /* default DGS_VGICP_DIRECT1 (FastVGICP constructor) */
   double vgicp_resolution;                 /* setResolution(reg_resolution), factory default 1.0 (registrations.cpp:52) */
-  /* ---- four details of un-vendored upstream code behind named switches (ABI 5; [UPSTREAM-RECALL]).  Each
+  /* ---- five details of un-vendored upstream code behind named switches (ABI 5; [UPSTREAM-RECALL]).  Each
    * defaults to what the published upstream source does as far as it can be recalled; 0 restores the stand-in of ABI <= 4. ---- */
   int32_t ndt_newton_solver;            /* upstream evaluation orders (ndt_strict_order >= 1): 1 = Eigen::JacobiSVD's own two-sided Jacobi sequence
                                            (what computeTransformation's `sv.solve(-score_gradient)` runs); 0 = one-sided Hestenes Jacobi.  The FAST
@@ -134,6 +134,11 @@ typedef struct dgs_params {
                                            float in [-104, 0] (tests/test_oracle_round4.py); 0 = the platform-independent polynomial of ABI <= 4
                                            (correctly rounded but for ~1e-9 of the arguments: NOT what a libm returns).  The FAST order uses the
                                            device library's expf either way.  (Was reserved0: same struct size.) */
+  int32_t ndt_cov_eigensolver;          /* voxel covariances (VoxelGridCovariance: `eigensolver.compute(leaf.cov_)`, all orders): 1 = Eigen 3.3's
+                                           SelfAdjointEigenSolver<Matrix3d>::compute restated -- scaling, the 3x3 Householder tridiagonalisation,
+                                           implicit QR steps with Wilkinson's shift, selection sort; 0 = cyclic Jacobi (ABI <= 4).  The eigenvectors
+                                           matter where a flat voxel's covariance is rebuilt from them (eigenvalue clamp). */
+  int32_t reserved1;
 } dgs_params;
 
 /* What the callers read back after align(): hasConverged(), getFinalTransformation(), and the

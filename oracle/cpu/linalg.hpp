@@ -3,7 +3,7 @@
 //
 // Small dense f64 linear algebra used by the CPU restatement of NDT_OMP / FAST_GICP.  It replaces the
 // Eigen calls the upstream libraries make (Eigen is absent from this image):
-//   SelfAdjointEigenSolver<Matrix3d>   -> sym_eig3   (cyclic Jacobi, ascending eigenvalues)
+//   SelfAdjointEigenSolver<Matrix3d>   -> eigen_selfadjoint3 (Eigen's tridiagonalisation + implicit QR, restated; round 4) / sym_eig3 (cyclic Jacobi, rounds 1-3)
 //   Matrix3d::inverse()                -> inv3       (cofactor form, as Eigen's fixed-size 3x3)
 //   JacobiSVD<Matrix<double,6,6>>::solve -> jsvd_solve6 (Eigen's own two-sided Jacobi sequence, restated; the default) or
 //                                          svd_solve6 (one-sided Hestenes Jacobi, rounds 1-3's stand-in; NdtParams::newton_solver = 0)
@@ -88,6 +88,127 @@ inline void sym_eig3(const double* Ain, double* evals, double* V) {
     for (int r = 0; r < 3; r++) Vs[r * 3 + k] = V[r * 3 + idx[k]];
   }
   std::memcpy(V, Vs, sizeof(Vs));
+}
+
+// ---- Eigen::SelfAdjointEigenSolver<Matrix3d>::compute(A, ComputeEigenvectors) restated (Eigen 3.3.x; [UPSTREAM-RECALL]) --------------------
+// What pclomp's VoxelGridCovariance runs on every voxel covariance (`eigensolver.compute(leaf.cov_)`): NOT the closed form (computeDirect) but the
+// generic path -- the lower triangle divided by its largest |entry|, the 3 x 3 Householder tridiagonalisation written out in
+// tridiagonalization_inplace_selector<MatrixType, 3, false>, implicit symmetric QR steps with Wilkinson's shift (tridiagonal_qr_step: Givens
+// rotations by JacobiRotation::makeGivens, the eigenvector matrix updated by applyOnTheRight) until every sub-diagonal entry is negligible
+// (|e_i| <= 2 eps (|d_i| + |d_i+1|) or <= DBL_MIN), eigenvalues scaled back, selection sort ascending with the columns swapped along.
+// Operation for operation as recalled from SelfAdjointEigenSolver.h / Tridiagonalization.h / Jacobi.h of Eigen 3.3.7 (Ubuntu 20.04's); not
+// checkable here (no Eigen in the image).  evals ascending; V row-major, column k = eigenvector of evals[k].  Returns the QR steps taken.
+inline int eigen_selfadjoint3(const double* Ain, double* evals, double* V) {
+  // mat = lower triangle of A (the strict upper part is never read), scaled into [-1, 1]
+  double m00 = Ain[0], m10 = Ain[3], m11 = Ain[4], m20 = Ain[6], m21 = Ain[7], m22 = Ain[8];
+  double scale = std::fabs(m00);
+  for (double v : {m10, m11, m20, m21, m22}) scale = std::fabs(v) > scale ? std::fabs(v) : scale;   // cwiseAbs().maxCoeff() of the lower-triangular copy (zeros above)
+  if (scale == 0.0) scale = 1.0;
+  m00 /= scale; m10 /= scale; m11 /= scale; m20 /= scale; m21 /= scale; m22 /= scale;
+  double diag[3], sub[2], Q[9];
+  const double tol = std::numeric_limits<double>::min();
+  diag[0] = m00;
+  const double v1norm2 = m20 * m20;
+  if (v1norm2 <= tol) {
+    diag[1] = m11; diag[2] = m22; sub[0] = m10; sub[1] = m21;
+    for (int i = 0; i < 9; i++) Q[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  } else {
+    const double beta = std::sqrt(m10 * m10 + v1norm2);
+    const double invBeta = 1.0 / beta;
+    const double m01 = m10 * invBeta, m02 = m20 * invBeta;
+    const double q = 2.0 * m01 * m21 + m02 * (m22 - m11);
+    diag[1] = m11 + m02 * q;
+    diag[2] = m22 - m02 * q;
+    sub[0] = beta;
+    sub[1] = m21 - m01 * q;
+    Q[0] = 1; Q[1] = 0; Q[2] = 0; Q[3] = 0; Q[4] = m01; Q[5] = m02; Q[6] = 0; Q[7] = m02; Q[8] = -m01;
+  }
+  // computeFromTridiagonal_impl
+  const int n = 3, maxIterations = 30;
+  int end = n - 1, start = 0, iter = 0;
+  const double considerAsZero = std::numeric_limits<double>::min(), precision = 2.0 * std::numeric_limits<double>::epsilon();
+  while (end > 0) {
+    for (int i = start; i < end; ++i)
+      if (std::fabs(sub[i]) <= (std::fabs(diag[i]) + std::fabs(diag[i + 1])) * precision || std::fabs(sub[i]) <= considerAsZero) sub[i] = 0.0;
+    while (end > 0 && sub[end - 1] == 0.0) end--;
+    if (end <= 0) break;
+    iter++;
+    if (iter > maxIterations * n) break;
+    start = end - 1;
+    while (start > 0 && sub[start - 1] != 0.0) start--;
+    // tridiagonal_qr_step(diag, sub, start, end, Q, n)
+    const double td = (diag[end - 1] - diag[end]) * 0.5;
+    const double e = sub[end - 1];
+    double mu = diag[end];
+    if (td == 0.0) {
+      mu -= std::fabs(e);
+    } else {
+      const double e2 = e * e;
+      // numext::hypot(td, e): p = max(|td|, |e|), p * sqrt(1 + (min / p)^2)
+      const double at = std::fabs(td), ae = std::fabs(e);
+      const double p = at > ae ? at : ae;
+      double h = 0.0;
+      if (p != 0.0) {
+        const double qp = (at > ae ? ae : at) / p;
+        h = p * std::sqrt(1.0 + qp * qp);
+      }
+      if (e2 == 0.0) mu -= (e / (td + (td > 0.0 ? 1.0 : -1.0))) * (e / h);
+      else mu -= e2 / (td + (td > 0.0 ? h : -h));
+    }
+    double x = diag[start] - mu;
+    double z = sub[start];
+    for (int k = start; k < end; ++k) {
+      // JacobiRotation::makeGivens(x, z)
+      double c, sn;
+      if (z == 0.0) {
+        c = x < 0.0 ? -1.0 : 1.0; sn = 0.0;
+      } else if (x == 0.0) {
+        c = 0.0; sn = z < 0.0 ? 1.0 : -1.0;
+      } else if (std::fabs(x) > std::fabs(z)) {
+        const double t = z / x;
+        double u = std::sqrt(1.0 + t * t);
+        if (x < 0.0) u = -u;
+        c = 1.0 / u; sn = -t * c;
+      } else {
+        const double t = x / z;
+        double u = std::sqrt(1.0 + t * t);
+        if (z < 0.0) u = -u;
+        sn = -1.0 / u; c = -t * sn;
+      }
+      // T = G' T G
+      const double sdk = sn * diag[k] + c * sub[k];
+      const double dkp1 = sn * sub[k] + c * diag[k + 1];
+      diag[k] = c * (c * diag[k] - sn * sub[k]) - sn * (c * sub[k] - sn * diag[k + 1]);
+      diag[k + 1] = sn * sdk + c * dkp1;
+      sub[k] = c * sdk - sn * dkp1;
+      if (k > start) sub[k - 1] = c * sub[k - 1] - sn * z;
+      x = sub[k];
+      if (k < end - 1) {
+        z = -sn * sub[k + 1];
+        sub[k + 1] = c * sub[k + 1];
+      }
+      // Q = Q * G: columns k, k + 1 (applyOnTheRight(k, k + 1, rot): x_i' = c x_i - s y_i, y_i' = s x_i + c y_i)
+      for (int i = 0; i < 3; i++) {
+        const double xi = Q[i * 3 + k], yi = Q[i * 3 + k + 1];
+        Q[i * 3 + k] = c * xi - sn * yi;
+        Q[i * 3 + k + 1] = sn * xi + c * yi;
+      }
+    }
+  }
+  for (int i = 0; i < 3; i++) diag[i] *= scale;
+  // selection sort, ascending, eigenvector columns swapped along (minCoeff: the FIRST smallest of the remaining segment)
+  for (int i = 0; i < n - 1; ++i) {
+    int k = 0;
+    for (int j = 1; j < n - i; j++)
+      if (diag[i + j] < diag[i + k]) k = j;
+    if (k > 0) {
+      std::swap(diag[i], diag[k + i]);
+      for (int r = 0; r < 3; r++) std::swap(Q[r * 3 + i], Q[r * 3 + k + i]);
+    }
+  }
+  for (int i = 0; i < 3; i++) evals[i] = diag[i];
+  std::memcpy(V, Q, sizeof(Q));
+  return iter;
 }
 
 // ---- exp(float), rounds 1-3's stand-in (NdtParams::exp_libm = 0) ---------------------------------------

@@ -116,7 +116,8 @@ void NdtCpu::set_target(const float* xyz16, int64_t n) {
         leaf.cov[a * 3 + b] = c * ((np - 1.0) / np);
       }
     double ev[3], V[9];
-    sym_eig3(leaf.cov, ev, V);
+    if (prm.cov_eigensolver) eigen_selfadjoint3(leaf.cov, ev, V);
+    else sym_eig3(leaf.cov, ev, V);
     if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) continue;  // nr_points = -1 upstream
     const double min_ev = prm.min_covar_eigvalue_mult * ev[2];
     if (ev[0] < min_ev) {

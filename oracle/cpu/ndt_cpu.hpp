@@ -41,6 +41,8 @@ struct NdtParams {
                                          // Hessian in index order), as ndt_omp kept it; 0 = the float computeDerivatives pass run again (rounds 1-3)
   int guess_rotation_polar = 1;          // initial p: Euler angles of Affine3f::rotation() = the polar factor of the guess's 3x3 (a float JacobiSVD);
                                          // 0 = Euler angles of the raw 3x3 (rounds 1-3)
+  int cov_eigensolver = 1;               // voxel covariances: 1 = Eigen::SelfAdjointEigenSolver<Matrix3d>::compute restated (tridiagonalisation + implicit QR,
+                                         // linalg.hpp eigen_selfadjoint3), 0 = cyclic Jacobi (rounds 1-3's stand-in)
 };
 
 struct Leaf {

@@ -31,6 +31,7 @@ void orc_ndt_default_params(orc_ndt_params* p) {
   p->newton_solver = d.newton_solver;
   p->hessian_recompute_double = d.hessian_recompute_double;
   p->guess_rotation_polar = d.guess_rotation_polar;
+  p->cov_eigensolver = d.cov_eigensolver;
 }
 
 void* orc_ndt_create(const orc_ndt_params* p) {
@@ -51,6 +52,7 @@ void* orc_ndt_create(const orc_ndt_params* p) {
   d.newton_solver = p->newton_solver;
   d.hessian_recompute_double = p->hessian_recompute_double;
   d.guess_rotation_polar = p->guess_rotation_polar;
+  d.cov_eigensolver = p->cov_eigensolver;
   return new NdtCpu(d);
 }
 void orc_ndt_destroy(void* h) { delete static_cast<NdtCpu*>(h); }
@@ -190,6 +192,7 @@ long long orc_glibc_expf_mismatches(uint32_t first_bits, uint32_t last_bits, uin
 }
 void orc_ldlt_solve6(const double* A, const double* b, double* x) { ldlt_solve6(A, b, x); }
 void orc_sym_eig3(const double* A, double* ev, double* V) { sym_eig3(A, ev, V); }
+int orc_eigen_selfadjoint3(const double* A, double* ev, double* V) { return eigen_selfadjoint3(A, ev, V); }
 int32_t orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -12,6 +12,7 @@ typedef struct orc_ndt_params {
   double resolution, step_size, outlier_ratio, transformation_epsilon, min_covar_eigvalue_mult;
   int32_t max_iterations, search_method, min_points_per_voxel, line_search, mt_max_step_iterations, num_threads, fix_hessian_d1, exp_libm;
   int32_t newton_solver, hessian_recompute_double, guess_rotation_polar;   /* round 4: NdtParams in ndt_cpu.hpp */
+  int32_t cov_eigensolver, pad0;
 } orc_ndt_params;
 
 typedef struct orc_result {
@@ -43,6 +44,7 @@ float orc_glibc_expf(float x);   /* linalg.hpp glibc_expf: std::exp(float) as gl
 long long orc_glibc_expf_mismatches(uint32_t first_bits, uint32_t last_bits, uint32_t* first_bad);   /* ... against the host libm, float by float */
 void orc_ldlt_solve6(const double* A36, const double* b6, double* x6);
 void orc_sym_eig3(const double* A9, double* evals3, double* V9);
+int orc_eigen_selfadjoint3(const double* A9, double* evals3, double* V9);   /* Eigen's SelfAdjointEigenSolver<Matrix3d>::compute restated; returns the QR steps */
 int32_t orc_max_threads(void);
 
 typedef struct orc_gicp_params {

@@ -39,7 +39,8 @@ class NdtParams(C.Structure):
                 ("max_iterations", C.c_int32), ("search_method", C.c_int32), ("min_points_per_voxel", C.c_int32),
                 ("line_search", C.c_int32), ("mt_max_step_iterations", C.c_int32), ("num_threads", C.c_int32),
                 ("fix_hessian_d1", C.c_int32), ("exp_libm", C.c_int32),
-                ("newton_solver", C.c_int32), ("hessian_recompute_double", C.c_int32), ("guess_rotation_polar", C.c_int32)]
+                ("newton_solver", C.c_int32), ("hessian_recompute_double", C.c_int32), ("guess_rotation_polar", C.c_int32),
+                ("cov_eigensolver", C.c_int32), ("pad0", C.c_int32)]
 
 
 class GicpParams(C.Structure):
@@ -105,7 +106,7 @@ class NdtOracle:
     def __init__(self, resolution=1.0, transformation_epsilon=0.01, max_iterations=64, search_method="DIRECT7",
                  step_size=0.1, outlier_ratio=0.55, line_search=1, num_threads=0, min_points_per_voxel=6,
                  min_covar_eigvalue_mult=0.01, mt_max_step_iterations=10, fix_hessian_d1=0, perturbed=False, exp_libm=1,
-                 newton_solver=1, hessian_recompute_double=1, guess_rotation_polar=1):
+                 newton_solver=1, hessian_recompute_double=1, guess_rotation_polar=1, cov_eigensolver=1):
         L = lib(perturbed)
         self._L = L
         p = NdtParams()
@@ -127,6 +128,7 @@ class NdtOracle:
         p.newton_solver = newton_solver
         p.hessian_recompute_double = hessian_recompute_double
         p.guess_rotation_polar = guess_rotation_polar
+        p.cov_eigensolver = cov_eigensolver   # voxel covariances: Eigen's SelfAdjointEigenSolver restated (1) / cyclic Jacobi (0)
         self.params = p
         self.max_iterations = max_iterations
         self._h = C.c_void_p(L.orc_ndt_create(C.byref(p)))
@@ -300,6 +302,17 @@ def sym_eig3(A):
     V = np.zeros((3, 3))
     lib().orc_sym_eig3(pa, ev.ctypes.data_as(C.POINTER(C.c_double)), V.ctypes.data_as(C.POINTER(C.c_double)))
     return ev, V
+
+
+def eigen_selfadjoint3(A):
+    """linalg.hpp eigen_selfadjoint3: Eigen::SelfAdjointEigenSolver<Matrix3d>::compute restated; (evals ascending, V, QR steps)."""
+    A, pa = _f64c(A)
+    ev = np.zeros(3)
+    V = np.zeros((3, 3))
+    L = lib()
+    L.orc_eigen_selfadjoint3.restype = C.c_int
+    it = int(L.orc_eigen_selfadjoint3(pa, ev.ctypes.data_as(C.POINTER(C.c_double)), V.ctypes.data_as(C.POINTER(C.c_double))))
+    return ev, V, it
 
 
 def max_threads() -> int:

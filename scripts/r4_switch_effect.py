@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How many of the 96 bench-shard pairs (seeds 40 / 1040 / 2040, 32 x 65,536 points) each of round 4's four oracle switches moves past
+"""How many of the 96 bench-shard pairs (seeds 40 / 1040 / 2040, 32 x 65,536 points) each of round 4's five oracle switches moves past
 north_star's gate (1e-4 m / 1e-5 rad), each switched on ALONE against the all-off oracle of rounds 1-3, and all together.  CPU only."""
 import json
 import os
@@ -13,9 +13,9 @@ from delta_graph_slam_amd import synth  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from tests.helpers import pose_error  # noqa: E402
 
-OFF = dict(newton_solver=0, hessian_recompute_double=0, guess_rotation_polar=0, exp_libm=0)
+OFF = dict(newton_solver=0, hessian_recompute_double=0, guess_rotation_polar=0, exp_libm=0, cov_eigensolver=0)
 CONFIGS = [("all off (rounds 1-3)", OFF), ("newton_solver", dict(OFF, newton_solver=1)), ("hessian_recompute_double", dict(OFF, hessian_recompute_double=1)),
-           ("guess_rotation_polar", dict(OFF, guess_rotation_polar=1)), ("exp_libm (glibc's expf)", dict(OFF, exp_libm=1)), ("all on (round 4 default)", {})]
+           ("guess_rotation_polar", dict(OFF, guess_rotation_polar=1)), ("exp_libm (glibc's expf)", dict(OFF, exp_libm=1)), ("cov_eigensolver (Eigen's tridiagonal QR)", dict(OFF, cov_eigensolver=1)), ("all on (round 4 default)", {})]
 only = os.environ.get("SWITCHES")
 if only:   # e.g. SWITCHES="exp_libm" : the all-off baseline + the named rows
     CONFIGS = [c for c in CONFIGS if c[0].startswith("all off") or any(c[0].startswith(o) for o in only.split(","))]

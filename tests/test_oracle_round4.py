@@ -156,3 +156,60 @@ def test_glibc_exp_restatement_equals_the_images_libm_on_a_fixed_stream_of_doubl
     for x in (-1.0, -0.5, -30.0, -600.0, -740.0, 0.0, 1e-300, 5.0, 709.0):
         assert orc.glibc_exp(x) == math.exp(x), x
     assert orc.glibc_exp(-800.0) == 0.0 and math.isinf(orc.glibc_exp(800.0)) and math.isnan(orc.glibc_exp(float("nan")))
+
+
+def test_eigen_selfadjoint3_restatement_is_an_eigen_decomposition_and_agrees_with_the_jacobi_stand_in():
+    """linalg.hpp eigen_selfadjoint3 ([UPSTREAM-RECALL]: Eigen 3.3's SelfAdjointEigenSolver<Matrix3d>::compute -- scaling, the written-out 3 x 3
+    tridiagonalisation, implicit QR with Wilkinson's shift, selection sort; no Eigen in the image to check the sequence against): on generic, flat
+    (planar voxels: the case the eigenvalue clamp rebuilds the covariance from), diagonal, repeated-eigenvalue and already-tridiagonal matrices it
+    IS an eigen-decomposition to rounding -- eigenvalues vs numpy.linalg.eigvalsh, residual A V - V diag, orthonormal V, ascending order -- and it
+    agrees with the cyclic-Jacobi stand-in (sym_eig3) to rounding; a handful of QR steps at most."""
+    rng = np.random.default_rng(0)
+    steps = []
+    for t in range(1500):
+        kind = t % 5
+        if kind == 0:
+            M = rng.normal(size=(3, 3))
+            A = M @ M.T
+        elif kind == 1:
+            R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+            A = R @ np.diag([1.0, 0.3, 1e-5 * rng.random()]) @ R.T
+        elif kind == 2:
+            A = np.diag(rng.random(3))
+        elif kind == 3:
+            R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+            A = R @ np.diag([2.0, 2.0, 0.5]) @ R.T * 1e-3
+        else:
+            A = np.diag(rng.random(3))
+            A[1, 0] = A[0, 1] = 0.1 * rng.random()
+        A = (A + A.T) / 2
+        ev, V, it = orc.eigen_selfadjoint3(A)
+        w = np.linalg.eigvalsh(A)
+        s = np.abs(w).max()
+        assert np.all(np.diff(ev) >= 0) and np.abs(ev - w).max() <= 4e-15 * s, (t, ev, w)
+        assert np.abs(A @ V - V * ev).max() <= 4e-15 * s and np.abs(V.T @ V - np.eye(3)).max() <= 4e-15, t
+        ev2, V2 = orc.sym_eig3(A)
+        assert np.abs(ev - ev2).max() <= 4e-15 * s
+        steps.append(it)
+    assert max(steps) <= 9 and min(steps) == 0
+    ev, V, it = orc.eigen_selfadjoint3(np.zeros((3, 3)))
+    assert np.array_equal(ev, np.zeros(3)) and np.array_equal(V, np.eye(3)) and it == 0
+    # only the lower triangle is read
+    A = np.array([[2.0, 9.0, 9.0], [0.3, 1.0, 9.0], [0.1, 0.2, 0.5]])
+    L = np.tril(A) + np.tril(A, -1).T
+    assert np.array_equal(orc.eigen_selfadjoint3(A)[0], orc.eigen_selfadjoint3(L)[0])
+
+
+def test_voxel_table_changes_only_by_rounding_with_the_eigen_solver_switch():
+    tgt, _, _ = synth.planar_pair(n=8192)
+    out = {}
+    for mode in (0, 1):
+        o = orc.NdtOracle(resolution=1.0, cov_eigensolver=mode)
+        o.set_target(tgt)
+        out[mode] = o.voxels()
+    assert orc.NdtOracle(resolution=1.0).params.cov_eigensolver == 1
+    assert np.array_equal(out[0]["keys"], out[1]["keys"]) and np.array_equal(out[0]["valid"], out[1]["valid"]) and np.array_equal(out[0]["mean"], out[1]["mean"])
+    v = out[0]["valid"]
+    assert v.sum() > 50
+    d = np.abs(out[0]["icov"][v] - out[1]["icov"][v]).max(axis=(1, 2) if out[0]["icov"].ndim == 3 else 1) / np.abs(out[0]["icov"][v]).reshape(v.sum(), -1).max(1)
+    assert d.max() <= 1e-9 and (d > 0).any()      # flat voxels are rebuilt from the eigenvectors: the two solvers' last bits show there

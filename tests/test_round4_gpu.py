@@ -1,7 +1,7 @@
 """-m gpu: round 4's upstream-order path against the CPU oracle.
 
-  * the four fidelity switches (dgs_params.ndt_newton_solver / ndt_hessian_recompute_double / ndt_guess_rotation_polar / ndt_exp_glibc), each
-    alone and all together, in ndt_strict_order 2 (every evaluation, the trajectory and the transform bit-identical) and 1 (transform bit-equal);
+  * the five fidelity switches (dgs_params.ndt_newton_solver / ndt_hessian_recompute_double / ndt_guess_rotation_polar / ndt_exp_glibc /
+    ndt_cov_eigensolver), each alone and all together, in ndt_strict_order 2 (every evaluation, the trajectory and the transform bit-identical) and 1 (transform bit-equal);
   * the double-precision computeHessian pass as a single evaluation (dgs_ndt_hessian_double): bit-identical sums in order 2, 1e-11 in order 1;
   * the launch structures of order 1 -- item-compacted kernel (default), lane-per-point kernels with the computeHessian launch in line or on its
     own stream, Newton steps in the closing workgroup or in ndt_strict_solve_kernel on the third stream, fused / unfused -- all give the
@@ -18,8 +18,8 @@ from delta_graph_slam_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-SW = ("ndt_newton_solver", "ndt_hessian_recompute_double", "ndt_guess_rotation_polar", "ndt_exp_glibc")
-OSW = ("newton_solver", "hessian_recompute_double", "guess_rotation_polar", "exp_libm")
+SW = ("ndt_newton_solver", "ndt_hessian_recompute_double", "ndt_guess_rotation_polar", "ndt_exp_glibc", "ndt_cov_eigensolver")
+OSW = ("newton_solver", "hessian_recompute_double", "guess_rotation_polar", "exp_libm", "cov_eigensolver")
 
 
 def _reg(**kw):
@@ -43,7 +43,7 @@ def _env(**kv):
     return E()
 
 
-@pytest.mark.parametrize("on", [(), (0,), (1,), (2,), (3,), (1, 3), (0, 1, 2), (0, 1, 2, 3)])
+@pytest.mark.parametrize("on", [(), (0,), (1,), (2,), (3,), (4,), (1, 3), (0, 1, 2), (0, 1, 2, 3, 4)])
 def test_switches_alone_and_together_against_the_oracle_with_the_same_switches(oracle_lib, on):
     tgt, src, Tgt = synth.kitti_pair(n_points=32768)
     guess = Tgt.copy().astype(np.float32)
