@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_derivatives_strict_kernel(const
       xt[2] = affine_row_rn(T[8], T[9], T[10], T[11], x.x, x.y, x.z);
       int vids[NB];
       const unsigned mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
-      strict_point_hd<SEARCH, true>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, rows + (size_t)pair * rows_pair_stride + (size_t)i * NB, row_stride, exp_libm != 0);
+      strict_point_hd<SEARCH, true>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, rows + (size_t)pair * rows_pair_stride + (size_t)i * NB, row_stride, exp_libm ? kGlibcExpTab : nullptr);
     }
     return;
   }

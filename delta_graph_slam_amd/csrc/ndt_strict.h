@@ -369,7 +369,7 @@ __device__ __forceinline__ void strict_point(const float4 x, const float (&xt)[3
 template <bool ROWS>
 __device__ __forceinline__ bool strict_item_hd(const float (&xt)[3], const double (&xj)[8], const double (&xh)[15], const double* __restrict__ rec,
                                                const double gauss_d1, const double gauss_d2, double (&acc)[kStrictAccum], double* __restrict__ rows, const size_t row_stride,
-                                               const bool exp_glibc) {
+                                               const unsigned long long* __restrict__ exptab_d) {
   const double pg13 = xj[0], pg23 = xj[1];
   const double pg4[3] = {xj[2], xj[3], xj[4]}, pg5[3] = {xj[5], xj[6], xj[7]};
   double q[3], C[3][3];
@@ -383,7 +383,7 @@ __device__ __forceinline__ bool strict_item_hd(const float (&xt)[3], const doubl
 #pragma unroll
   for (int r = 0; r < 3; r++) Cq[r] = C[r][0] * q[0] + C[r][1] * q[1] + C[r][2] * q[2];
   const double e_arg = -gauss_d2 * (q[0] * Cq[0] + q[1] * Cq[1] + q[2] * Cq[2]) / 2;
-  double e = gauss_d2 * (exp_glibc ? glibc_exp_dev(e_arg, kGlibcExpTab) : det_exp(e_arg));   // std::exp(double) as glibc computes it / rounds 1-3's polynomial
+  double e = gauss_d2 * (exptab_d ? glibc_exp_dev(e_arg, exptab_d) : det_exp(e_arg));   // std::exp(double) as glibc computes it (table: kGlibcExpTab or its LDS copy) / rounds 1-3's polynomial
   if (e > 1 || e < 0 || e != e) return false;
   e *= gauss_d1;
   // x_trans . (c_inv * point_hessian block) for the six distinct vectors a = (0, xh0, xh1) b c d = xh6..8 e f
@@ -442,7 +442,7 @@ __device__ __forceinline__ void strict_point_tables_hd(const float4 xf, const Nd
 template <int SEARCH, bool ROWS>
 __device__ __forceinline__ void strict_point_hd(const float4 xf, const float (&xt)[3], const int (&vids)[Offsets<SEARCH>::N], const unsigned mask_in, const NdtPair& st,
                                                 const double* __restrict__ vtab, const double gauss_d1, const double gauss_d2, double (&acc)[kStrictAccum],
-                                                double* __restrict__ rows, const size_t row_stride, const bool exp_glibc) {
+                                                double* __restrict__ rows, const size_t row_stride, const unsigned long long* __restrict__ exptab_d) {
   constexpr int NB = Offsets<SEARCH>::N;
   double xj[8], xh[15];
   strict_point_tables_hd(xf, st, xj, xh);
@@ -451,7 +451,7 @@ __device__ __forceinline__ void strict_point_hd(const float4 xf, const float (&x
     const int k = __ffs(mask) - 1;
     mask &= mask - 1u;
     bool ok = ((mask_in >> k) & 1u) != 0;
-    if (ok) ok = strict_item_hd<ROWS>(xt, xj, xh, vtab + (size_t)strict_pick(vids, k) * 12, gauss_d1, gauss_d2, acc, ROWS ? rows + k : nullptr, row_stride, exp_glibc);
+    if (ok) ok = strict_item_hd<ROWS>(xt, xj, xh, vtab + (size_t)strict_pick(vids, k) * 12, gauss_d1, gauss_d2, acc, ROWS ? rows + k : nullptr, row_stride, exptab_d);
     if (ROWS && !ok) {
       for (int en = 0; en < 36; en++) rows[(size_t)en * row_stride + k] = 0.0;
     }
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict_kernel(const float4* con
     int vids[NB];
     const unsigned mask = strict_neighbourhood<SEARCH>(xt, g, leaf_pow2, vids);
     if (!mask) continue;
-    if (HD) strict_point_hd<SEARCH, false>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, nullptr, 0, consts.exp_libm != 0);
+    if (HD) strict_point_hd<SEARCH, false>(x, xt, vids, mask, st, vtab, gauss_d1, gauss_d2, acc, nullptr, 0, consts.exp_libm ? kGlibcExpTab : nullptr);
     else if (kind == 1) strict_point<SEARCH, true>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc, exptab);
     else strict_point<SEARCH, false>(x, xt, vids, mask, st, vs, gauss_d1, gd2, acc, exptab);
   }
@@ -801,11 +801,15 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
 
   __shared__ __attribute__((aligned(16))) unsigned char s_tab[kBlock / kWave][TL::kTableBytes];
   __shared__ unsigned s_queue[kBlock / kWave][TL::kQueue];
-  // glibc's 2^(i/32) table in LDS: the item loop looks it up per lane (an LDS read instead of a gather through the vector cache)
+  // glibc's 2^(i/32) table in LDS: the item loop looks it up per lane (an LDS read instead of a gather through the vector cache).  Measured
+  // alternatives on the bench step, same box: one copy per wave written by the wave itself, no workgroup barrier: 5.45-5.46 ms against 5.37-5.39
+  // for this shared copy; the double pass's 2 x 128 table in LDS as well: 5.37 / 3.342 against 5.38 / 3.342 ms (bench step / 8 x 200,000
+  // points) for constant memory, where it therefore stays.
   __shared__ unsigned long long s_exp2f[32];
   if (threadIdx.x < 32) s_exp2f[threadIdx.x] = kGlibcExp2fTab[threadIdx.x];
   __syncthreads();
   const unsigned long long* __restrict__ exptab = s_exp2f;   // this kernel serves consts.exp_libm = 1 only (strict_kernel_version, ndt_align.hip)
+  const unsigned long long* __restrict__ exptab_d = kGlibcExpTab;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* tf = reinterpret_cast<float*>(s_tab[wave]);            // float kinds: [26][PTS]
   double* td = reinterpret_cast<double*>(s_tab[wave]);          // double pass: [23][PTS_HD] doubles, then [3][PTS_HD] floats
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
           for (int f = 0; f < 15; f++) xh[f] = td[(8 + f) * TL::PTS_HD + slot];
 #pragma unroll
           for (int f = 0; f < 3; f++) xt[f] = tdx[f * TL::PTS_HD + slot];
-          (void)strict_item_hd<false>(xt, xj, xh, vtab + (size_t)vid * 12, gauss_d1, gauss_d2, acc, nullptr, 0, true);
+          (void)strict_item_hd<false>(xt, xj, xh, vtab + (size_t)vid * 12, gauss_d1, gauss_d2, acc, nullptr, 0, exptab_d);
         } else {
           float xt[3], xj[8], xh[15];
 #pragma unroll
