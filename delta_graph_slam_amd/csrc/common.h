@@ -82,6 +82,16 @@ struct NdtSolver {
   double phi_0, d_phi_0;
   double a_t, a_l, f_l, g_l, a_u, f_u, g_u;
   double step_init;
+  // Upstream orders: the trial points of the current line search and what they evaluated to.  More-Thuente's step is clamped to
+  // [eps / 2, step_size], so a search often evaluates the SAME pose again -- on the CPU that gives the same doubles and updateIntervalMT's
+  // `f_t > f_l` is decided by equality; here the sums of two launches of different composition differ in their last bits (~1e-14), which
+  // flipped that test on 3 of ~700 pairs at transformation_epsilon = 0.1 (soak, profiles/r04).  A pose that was evaluated before in this line
+  // search takes its earlier value (ndt_advance); reset by begin_iteration.
+  static constexpr int kTrialCache = 3;
+  int trial_n, trial_next;
+  double trial_x[kTrialCache][6];
+  double trial_score[kTrialCache];
+  double trial_grad[kTrialCache][6];
 };
 
 struct NdtPair {

@@ -316,6 +316,7 @@ int dgs_create(const dgs_params* params, dgs_handle** out) {
   if (const char* e = std::getenv("DGS_NDT_HD_OVERLAP")) h->hd_overlap = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NDT_SOLVE_MIN_ACTIVE")) h->solve_min_active = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("DGS_NDT_SPECULATE")) h->ndt_speculate = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DGS_NDT_FIXED_SLICES")) h->ndt_fixed_slices = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NDT_QUEUE")) h->ndt_queue_mode = std::atoi(e);
   if (const char* e = std::getenv("DGS_NDT_SCHEDULE")) h->ndt_schedule = std::atoi(e) != 0;
   if (const char* e = std::getenv("DGS_NDT_QUEUE_MIN_PAIRS")) h->ndt_queue_min_pairs = std::max(1, std::atoi(e));

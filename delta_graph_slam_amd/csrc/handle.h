@@ -117,6 +117,7 @@ struct dgs_handle {
   int strict_kernel = 3;              // DGS_NDT_STRICT_KERNEL: upstream-order kernels: 3 item-compacted (one launch per round), 2 lane-per-point (two launches per round)
   bool hd_overlap = true;             // DGS_NDT_HD_OVERLAP=0: the computeHessian launch of a round in line with the round's first launch
   bool ndt_speculate = true;          // DGS_NDT_SPECULATE=0: upstream order, item-compacted kernel: the Newton step's Jacobi SVD in the closing workgroup instead of speculated
+  bool ndt_fixed_slices = false;     // DGS_NDT_FIXED_SLICES=1: upstream order, item-compacted kernel: a pair's slices are a function of its own size (ndt_strict.h strict_slices_of)
                                       // from the Gauss-Jordan direction and verified beside the next launch (NdtPair::spec_s)
   int solve_min_active = 0;           // DGS_NDT_SOLVE_MIN_ACTIVE (default 0 = the Newton step stays in the closing workgroup): item-compacted upstream-order kernel:
                                       // with at least this many pairs in a launch the Newton steps go to ndt_strict_solve_kernel on the third stream.  Measured on the

@@ -953,6 +953,8 @@ __device__ __forceinline__ bool begin_iteration(NdtPair* st, NdtPair* hdr, NdtSo
   }
   const double step_max = c.step_size, step_min = c.trans_eps / 2;
   s.step_iterations = 0;
+  s.trial_n = 0;
+  s.trial_next = 0;
   s.a_l = 0; s.a_u = 0;
   s.f_l = mt_psi(0, s.phi_0, s.phi_0, s.d_phi_0, kMu);
   s.g_l = mt_dpsi(s.d_phi_0, s.d_phi_0, kMu);
@@ -1025,6 +1027,30 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
   const bool resume = STRICT && s.phase == PH_SOLVE_PENDING;
   if (!resume) s.evaluations++;
+#ifndef DGS_AB_NO_TRIAL_CACHE
+  if (STRICT && (s.phase == PH_MT_FIRST || s.phase == PH_MT_TRIAL)) {
+    // a trial point this line search has evaluated before takes the value it had then (NdtSolver::trial_x): same pose, same doubles, as on the CPU
+    int hit = -1;
+    for (int k = 0; k < s.trial_n; k++) {
+      bool eq = true;
+#pragma unroll
+      for (int j = 0; j < 6; j++) eq = eq && (s.trial_x[k][j] == s.x_t[j]);
+      if (eq && hit < 0) hit = k;
+    }
+    if (hit >= 0) {
+      s.score = s.trial_score[hit];
+#pragma unroll
+      for (int j = 0; j < 6; j++) s.grad[j] = s.trial_grad[hit][j];
+    } else {
+      const int k = s.trial_next;
+#pragma unroll
+      for (int j = 0; j < 6; j++) { s.trial_x[k][j] = s.x_t[j]; s.trial_grad[k][j] = s.grad[j]; }
+      s.trial_score[k] = s.score;
+      s.trial_next = (k + 1) % NdtSolver::kTrialCache;
+      if (s.trial_n < NdtSolver::kTrialCache) s.trial_n++;
+    }
+  }
+#endif
   switch (resume ? PH_INIT_EVAL : s.phase) {
     case PH_PROBE:
       s.phase = PH_DONE;
@@ -1608,6 +1634,8 @@ __global__ void ndt_init_kernel(NdtPair* __restrict__ pairs, const NdtInit* __re
   NdtSolver s;
   s.phase = probe ? PH_PROBE : PH_INIT_EVAL;
   s.nr_iterations = 0;
+  s.trial_n = 0;
+  s.trial_next = 0;
   s.evaluations = 0;
   s.converged = 0;
   s.step_iterations = 0;
@@ -1881,6 +1909,17 @@ static void launch_strict_sums(dgs_handle* h, const NdtLaunch& L, const dim3 gri
     if (hd && launch >= 0) return;   // one kernel serves every kind (launch < 0: the test hook asks for the kind it has set up)
     const int spec = (launch >= 0 && h->ndt_speculate && h->consts.newton_solver && !strict_solve_beside(h)) ? 1 : 0;
     const dim3 grid_s(grid.x + (spec ? L.n_pairs : 0));   // + one solver workgroup per pair, in front (ndt_strict.h)
+    if (h->ndt_fixed_slices) {   // DGS_NDT_FIXED_SLICES=1: a pair's slices are a function of its own size (ndt_strict.h)
+      if (launch >= 0)
+        hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true, true, true>), grid_s, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
+                           h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
+                           h->done_flags, launch, strict_solve_beside(h) ? h->solve_min_active : 0, spec);
+      else
+        hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, false, true, true>), grid, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
+                           h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,
+                           h->done_counter.ptr, launch, 0, 0);
+    return;
+    }
     if (launch >= 0)
       hipLaunchKernelGGL((ndt_strict3_kernel<SEARCH, true, true>), grid_s, dim3(kBlock), 0, h->stream, h->src_ptrs.ptr, h->src_sizes.ptr, h->pairs.ptr, h->grid, h->vox_strict.ptr,
                          h->vox_dbg.ptr, h->consts.gauss_d1, h->consts.gauss_d2, leaf_pow2, h->partials.ptr, L.n_pairs, L.cap_blocks, h->pair_blocks.ptr, h->consts,

@@ -496,6 +496,47 @@ __device__ __forceinline__ void strict_block_row(const double (&acc)[kStrictAccu
   }
 }
 
+// The same reduction cut in two for the item-compacted kernel, whose workgroups write one row per SLICE and several slices each: the per-wave half
+// (no workgroup barrier: the four waves of a workgroup run through their tiles independently -- with a barrier per slice the step took 6.8 ms
+// instead of 5.4, the waves waiting for the slowest of the four at every slice) leaves the wave's column sums in LDS, slot by slot; the rows of
+// up to kStrictSlots slices are then written together behind ONE barrier, each row = ((wave 0 + wave 1) + wave 2) + wave 3 as before.
+constexpr int kStrictSlots = 4;
+__device__ __forceinline__ void strict_wave_cols(const double (&acc)[kStrictAccum], const int ncol, double* __restrict__ my, double* __restrict__ cols_of_wave) {
+  constexpr int CH = 11, RS = 65, NCH = 4;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int h = 0; h < NCH; h++) {
+    if (h * CH >= ncol) break;   // wave-uniform
+#pragma unroll
+    for (int k = 0; k < CH; k++) my[k * RS + lane] = (h * CH + k < kStrictAccum) ? acc[h * CH + k < kStrictAccum ? h * CH + k : 0] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    if (lane < CH) {
+      double v = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 64; j++) v += my[lane * RS + j];
+      cols_of_wave[h * CH + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+  }
+}
+// rows of slices q_first, q_first + q_step, ... (n_slots of them) from the waves' column sums; every thread of the workgroup calls it
+template <bool COHERENT>
+__device__ __forceinline__ void strict_rows_flush(const double (*cols)[kBlock / kWave][kStrictPad], const int n_slots, const int ncol, double* __restrict__ rows_of_pair,
+                                                  const int q_first, const int q_step) {
+  __syncthreads();
+  const int slot = threadIdx.x / kStrictPad, col = threadIdx.x % kStrictPad;
+  if (slot < n_slots) {
+    double v = 0.0;
+    if (col < ncol) v = ((cols[slot][0][col] + cols[slot][1][col]) + cols[slot][2][col]) + cols[slot][3][col];
+    double* row = rows_of_pair + (size_t)(q_first + slot * q_step) * kStrictPad + col;
+    if (COHERENT) handoff_store_row(row, v);
+    else *row = v;
+  }
+  __syncthreads();
+}
+
 // Sums a pair's rows in slice order and advances its optimiser by one evaluation (one whole workgroup; launch >= 0: inside the fused
 // launch, rows read with the hand-off's coherent loads, the pair leaves through last_launch + its host flag).
 // HD / ONE_KERNEL: which kernel of the round runs this closing -- see NdtPair::serve.  ONE_KERNEL (ndt_strict3_kernel): every evaluation
@@ -758,7 +799,23 @@ struct StrictTile {
   static constexpr int kQueue = PTS * NB;            // items of a tile at most
 };
 
-template <int SEARCH, bool FUSED, bool WITH_HD>
+// DGS_NDT_FIXED_SLICES=1 (dgs_handle::ndt_fixed_slices; off by default): the slices of a pair as a function of its OWN point count -- 512 points
+// per slice, at least 64 slices while every thread still has a point, at most the rows reserved per pair -- instead of "one slice per workgroup
+// the launch could spare".  A slice is the unit whose double sums make one row, so with fixed slices neither the workgroup that serves a slice
+// nor the composition of the launch enters the association of the sums: the same pose gives the same doubles in every launch, and a pair's
+// result does not depend on what else is in its batch (tests/test_round4_gpu.py).  It costs 20 % of the bench step (6.5 against 5.4 ms: four
+// per-slice reductions per workgroup instead of one while 32 pairs iterate), and the case that made it necessary -- More-Thuente comparing
+// the values of a REPEATED trial point, found by the soak at transformation_epsilon = 0.1 -- is closed for free by NdtSolver::trial_x, so it
+// stays an option for callers that need batch-independent bits.
+__device__ __forceinline__ int strict_slices_of(const int n, const int cap_blocks) {
+#ifndef DGS_STRICT_SLICE_PPT
+#define DGS_STRICT_SLICE_PPT 2   // points per thread and slice (A/B: make ab AB=-DDGS_STRICT_SLICE_PPT=8)
+#endif
+  const int by_points = (n + DGS_STRICT_SLICE_PPT * kBlock - 1) / (DGS_STRICT_SLICE_PPT * kBlock), at_least = min(64 * 2 / DGS_STRICT_SLICE_PPT, (n + kBlock - 1) / kBlock);
+  return max(1, min(max(by_points, at_least), cap_blocks));
+}
+
+template <int SEARCH, bool FUSED, bool WITH_HD, bool FIXED = false>
 __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* const* __restrict__ src_ptrs, const int* __restrict__ src_sizes, NdtPair* __restrict__ pairs,
                                                                const VoxelGrid g, const VoxelStrictRec* __restrict__ vs, const double* __restrict__ vtab,
                                                                const double gauss_d1, const double gauss_d2, const int leaf_pow2, double* __restrict__ partials,
@@ -785,11 +842,13 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
     blocks_per_pair = max(1, min(((int)gridDim.x - n_solvers) / n_active, cap_blocks));   // as deal_workgroup derives it
   } else {
     if (!deal_workgroup(n_pairs, cap_blocks, in_round, pair, slice, blocks_per_pair, &n_active, (int)blockIdx.x - n_solvers, (int)gridDim.x - n_solvers)) return;
-    if (slice == 0 && threadIdx.x == 0) pair_blocks[pair] = blocks_per_pair;
   }
   const NdtPair& st = pairs[pair];
   const float4* __restrict__ src = src_ptrs[pair];
   const int n = src_sizes[pair];
+  // rows of the pair: the workgroups it was dealt in THIS launch (default), or -- dgs_handle::ndt_fixed_slices -- a function of its own size
+  const int n_slices = FIXED ? strict_slices_of(n, cap_blocks) : blocks_per_pair;   // (FIXED: its own instantiation -- as a run-time switch the default path lost 5 %)
+  if (!solver && slice == 0 && threadIdx.x == 0) pair_blocks[pair] = n_slices;
   const int kind = WITH_HD ? st.need_hessian : (st.need_hessian != 0 ? 1 : 0);
   const float gd2 = (float)gauss_d2;
   float T[12];
@@ -842,10 +901,19 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
     __builtin_amdgcn_wave_barrier();
   }
   const int subs = pts / 64;
-  const int stride = blocks_per_pair * kBlock;
-  // the wave's points: i = first + lane + sub * stride, tiles of `subs` strides
+  const int stride = n_slices * kBlock;
+  static_assert(TL::kTableBytes >= kStrictRowScratch * 8, "the wave's table region doubles as its reduction scratch");
+  // this workgroup's slices q = slice, slice + blocks_per_pair, ...: each its own sums and its own row
+  __shared__ double s_cols[FIXED ? kStrictSlots : 1][FIXED ? kBlock / kWave : 1][FIXED ? kStrictPad : 1];
+  static_assert(kStrictSlots * kStrictPad <= kBlock, "one thread per entry of the rows written together");
+  int slot = 0, q_first = slice;
 #pragma unroll 1
-  for (int first = solver ? n : slice * kBlock + wave * 64; first < n; first += subs * stride) {
+  for (int q = solver ? n_slices : slice; FIXED ? (q < n_slices) : (q == slice && !solver); q += blocks_per_pair) {
+#pragma unroll
+  for (int k = 0; k < kStrictAccum; k++) acc[k] = 0.0;
+  // the wave's points of slice q: i = first + lane + sub * stride, tiles of `subs` strides
+#pragma unroll 1
+  for (int first = q * kBlock + wave * 64; first < n; first += subs * stride) {
     int qn = 0;
 #pragma unroll 1
     for (int sub = 0; sub < subs; sub++) {
@@ -945,8 +1013,19 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
     }
     __builtin_amdgcn_wave_barrier();   // the next tile overwrites the tables and the queue (LDS operations of one wave stay in order)
   }
-  static_assert(TL::kTableBytes >= kStrictRowScratch * 8, "the wave's table region doubles as its reduction scratch");
-  if (!solver) strict_block_row<FUSED, false>(acc, kind ? kStrictAccum : 7, partials + ((size_t)pair * cap_blocks + slice) * kStrictPad, td);
+  if (FIXED) {
+    strict_wave_cols(acc, kind ? kStrictAccum : 7, td, s_cols[slot][wave]);
+    slot++;
+    if (slot == kStrictSlots || q + blocks_per_pair >= n_slices) {   // workgroup-uniform
+      strict_rows_flush<FUSED>(reinterpret_cast<const double (*)[kBlock / kWave][kStrictPad]>(&s_cols[0][0][0]), slot, kind ? kStrictAccum : 7,
+                               partials + (size_t)pair * cap_blocks * kStrictPad, q_first, blocks_per_pair);
+      slot = 0;
+      q_first = q + blocks_per_pair;
+    }
+  } else {
+    strict_block_row<FUSED, false>(acc, kind ? kStrictAccum : 7, partials + ((size_t)pair * cap_blocks + slice) * kStrictPad, td);
+  }
+  }
   if (!FUSED) return;
   __shared__ int s_last;
   if (threadIdx.x < kStrictPad) handoff_drain_stores();   // (solver: the exact state's write-through stores)
@@ -960,7 +1039,7 @@ __global__ __launch_bounds__(kBlock, 2) void ndt_strict3_kernel(const float4* co
   if (threadIdx.x == 0 && pairs[pair].s.nr_iterations == 1) pairs[pair].traj[kTrajCap - 1][5] = (double)wall_clock64();
 #endif
   // with enough other pairs to keep the chip busy the Newton step (a ~40 us dependent chain on one wave) leaves the launch: solve_min_active > 0
-  ndt_close_strict<false, WITH_HD>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, blocks_per_pair, consts, done_flags + pair, launch, 1,
+  ndt_close_strict<false, WITH_HD>(pairs + pair, partials + (size_t)pair * cap_blocks * kStrictPad, n_slices, consts, done_flags + pair, launch, 1,
                                    solve_min_active > 0 && n_active >= solve_min_active, speculate != 0);
 }
 

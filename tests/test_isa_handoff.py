@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "delta_graph_slam_amd", "csrc")
 
 KERNELS = {
     "ndt_align.s": ["_ZN3dgs22ndt_derivatives_kernelILi%dELb1ELb0EE" % s for s in (0, 1, 2, 3)]           # <search, fused, scalar>
-                   + ["_ZN3dgs18ndt_strict3_kernelILi%dELb1ELb1EE" % s for s in (0, 1, 2, 3)]            # upstream order, item-compacted: <search, fused, with the double pass>
+                   + ["_ZN3dgs18ndt_strict3_kernelILi%dELb1ELb1ELb%dEE" % (s, f) for s in (0, 1, 2, 3) for f in (0, 1)]   # upstream order, item-compacted: <search, fused, with the double pass, fixed slices>
                    + ["_ZN3dgs17ndt_strict_kernelILi2ELb1ELb%dEE" % hd for hd in (0, 1)],                  # upstream order, lane-per-point: <DIRECT7, fused, float kinds / double pass>
     "gicp.s": ["_ZN3dgs21gicp_linearize_kernelILb1EE", "_ZN3dgs22vgicp_linearize_kernelILb1EE"],
 }
@@ -68,7 +68,7 @@ def test_fused_kernels_hand_their_rows_over_in_the_documented_order(asm, file, p
 
 
 def test_unfused_kernels_do_not_pay_for_the_hand_off(asm):
-    for file, prefix in (("ndt_align.s", "_ZN3dgs22ndt_derivatives_kernelILi2ELb0ELb0EE"), ("ndt_align.s", "_ZN3dgs18ndt_strict3_kernelILi2ELb0ELb1EE"),
+    for file, prefix in (("ndt_align.s", "_ZN3dgs22ndt_derivatives_kernelILi2ELb0ELb0EE"), ("ndt_align.s", "_ZN3dgs18ndt_strict3_kernelILi2ELb0ELb1ELb0EE"), ("ndt_align.s", "_ZN3dgs18ndt_strict3_kernelILi2ELb0ELb1ELb1EE"),
                          ("gicp.s", "_ZN3dgs21gicp_linearize_kernelILb0EE")):
         ln = _body(asm[file], prefix)
         assert not any(re.search(r"\bsc1\b|global_atomic", x) for x in ln), prefix

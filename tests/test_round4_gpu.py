@@ -181,3 +181,59 @@ def test_refused_speculated_step_is_taken_again_exactly(oracle_lib):
     spec.setInputSource(big_s)
     spec.align()
     assert spec.last_result.iterations == rb["iterations"] and np.array_equal(spec.getFinalTransformation(), rb["T"])
+
+
+def _soak_batch(index, seed=31337):
+    """Batch `index` of scripts/r4_soak.py --seed 31337 --vary-params (the stream that found the case below)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("r4_soak", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "r4_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for b, kind, res, search, tgt, sources, guesses, kw in mod.batches(index + 1, seed, True):
+        if b == index:
+            return res, search, tgt, sources, guesses, kw
+
+
+def test_repeated_trial_point_of_a_clamped_line_search_takes_its_earlier_value(oracle_lib):
+    """At transformation_epsilon = 0.1 (the reference launch file's value) More-Thuente's step is clamped to [0.05, step_size] and a line search
+    evaluates the SAME pose more than once; on the CPU the two evaluations are the same doubles and updateIntervalMT's `f_t > f_l` is decided by
+    equality.  In order 1 the sums of two launches of different composition differ in their last bits, which sent pair 28 of this batch (32 x
+    16,384 points, 0.5 m, DIRECT1; found by scripts/r4_soak.py --vary-params) through 9 evaluations instead of 6 and 0.11 m away from the CPU's
+    answer.  A pose evaluated before in the same line search now takes its earlier value (NdtSolver::trial_x): every pair equals the oracle's
+    iterations, evaluations and transform -- and so does the run with fixed slices (DGS_NDT_FIXED_SLICES=1), which removes the dependence on the
+    launch composition altogether."""
+    res, search, tgt, sources, guesses, kw = _soak_batch(6)
+    assert kw["transformation_epsilon"] == 0.1 and len(sources) == 32
+    o = oracle_lib.NdtOracle(resolution=res, search_method=search, line_search=kw["ndt_line_search"], max_iterations=kw["maximum_iterations"],
+                             transformation_epsilon=kw["transformation_epsilon"], step_size=kw["ndt_step_size"])
+    o.set_target(tgt)
+    ref = []
+    for s in sources:
+        o.set_source(s)
+        ref.append(o.align(guesses[len(ref)]))
+    for env in ({}, {"DGS_NDT_FIXED_SLICES": 1}):
+        with _env(**env):
+            r = _reg(ndt_strict_order=1, **kw)
+        r.setInputTarget(tgt)
+        got = r.align_batch(sources, guesses)
+        for c, (x, y) in enumerate(zip(got, ref)):
+            assert (x["iterations"], x["evaluations"]) == (y["iterations"], y["evaluations"]) and np.array_equal(x["T"], y["T"]), (env, c)
+
+
+def test_fixed_slices_make_a_pairs_doubles_independent_of_its_batch(oracle_lib):
+    """DGS_NDT_FIXED_SLICES=1: the slices of a pair are a function of its own size, so its sums -- score included, bit for bit -- are the same alone,
+    in a batch of 5 and in a batch of 24 (the default deals a pair as many workgroups as the launch can spare: same transforms, other last bits)."""
+    tgt, sources, guesses, _ = synth.loop_batch(n_candidates=24, n_points=16384, seed=91, distinct_scans=6)
+    sources = list(sources)
+    sources[3] = sources[3][:9001]
+    with _env(DGS_NDT_FIXED_SLICES=1):
+        r = _reg(ndt_strict_order=1)
+    r.setInputTarget(tgt)
+    big = r.align_batch(sources, guesses)
+    small = r.align_batch(sources[:5], guesses[:5])
+    for c in range(5):
+        assert big[c]["score"] == small[c]["score"] and np.array_equal(big[c]["T"], small[c]["T"]) and big[c]["evaluations"] == small[c]["evaluations"], c
+    for c in (0, 3, 17):
+        r.setInputSource(sources[c])
+        r.align(guesses[c])
+        assert r.last_result.score == big[c]["score"] and np.array_equal(r.getFinalTransformation(), big[c]["T"]), c
