@@ -1027,8 +1027,11 @@ __device__ __forceinline__ void ndt_advance(NdtPair* st, NdtPair* hdr, NdtSolver
   bool iteration_open = false;  // true: an iteration's line search has accepted its step, close it
   const bool resume = STRICT && s.phase == PH_SOLVE_PENDING;
   if (!resume) s.evaluations++;
+#ifndef DGS_TRIAL_CACHE_ALL_ORDERS
+#define DGS_TRIAL_CACHE_ALL_ORDERS 0
+#endif
 #ifndef DGS_AB_NO_TRIAL_CACHE
-  if (STRICT && (s.phase == PH_MT_FIRST || s.phase == PH_MT_TRIAL)) {
+  if ((STRICT || DGS_TRIAL_CACHE_ALL_ORDERS) && (s.phase == PH_MT_FIRST || s.phase == PH_MT_TRIAL)) {
     // a trial point this line search has evaluated before takes the value it had then (NdtSolver::trial_x): same pose, same doubles, as on the CPU
     int hit = -1;
     for (int k = 0; k < s.trial_n; k++) {

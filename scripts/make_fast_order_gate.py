@@ -30,13 +30,16 @@ for seed in (40, 1040, 2040):
     for c in range(32):
         o.set_source(sources[c])
         To.append(o.align(guesses[c])["T"])
-    r = Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=0)
+    r = Registration("NDT_OMP", ndt_resolution=1.0, ndt_strict_order=0, **({"lib_path": os.environ["DGS_GATE_LIB"]} if os.environ.get("DGS_GATE_LIB") else {}))
     r.setInputTarget(tgt)
     res = r.align_batch(list(sources), guesses)
     err = np.array([pose_error(res[c]["T"], To[c]) for c in range(32)])
     outside = [int(c) for c in np.nonzero((err[:, 0] > TOL_M) | (err[:, 1] > TOL_RAD))[0]]
     shard = {"pairs_inside": 32 - len(outside), "outside": {}}
     for c in outside:
+        if os.environ.get("DGS_GATE_NO_BANDS"):
+            print(seed, c, err[c], flush=True)
+            continue
         _, bt, br = orc.ndt_band(tgt, sources[c], guesses[c], twins=TWINS, resolution=1.0)
         shard["outside"][str(c)] = {"error_m_rad": [float(err[c, 0]), float(err[c, 1])], "oracle_band_m_rad": [float(bt), float(br)]}
         print(seed, c, err[c], bt, br, flush=True)
