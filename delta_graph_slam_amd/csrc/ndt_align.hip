@@ -2060,7 +2060,7 @@ static int ndt_setup(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_h
     choose_queue(h, L);
     DGS_HIP_TRY(h, h->ndt_queue.reserve(2 * ((size_t)n_pairs + 2) + kQueueStatInts));
     // one record slot per pair and round; a registration ends within (max_iterations + 2) x (line-search trials + 2) evaluations
-    const int per_iter_q = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
+    const int per_iter_q = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP && h->prm.ndt_step_size - h->prm.transformation_epsilon / 2 > 0) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
     h->ndt_ring_rounds = (h->prm.maximum_iterations + 3) * per_iter_q + 8;
     DGS_HIP_TRY(h, h->ndt_ring.reserve((size_t)n_pairs * h->ndt_ring_rounds * kQueueSlotBytes));
   }
@@ -2201,7 +2201,11 @@ int ndt_align_pairs(dgs_handle* h, int n_pairs, const float4* const* src_ptrs_ho
     for (int i = 0; i < n_pairs; i++) h->done_flags[i] = 0;   // nothing of this handle is in flight: the previous align has been synchronised
   }
   hipEvent_t* ev = h->ev_poll;
-  const int per_iter = (h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP) ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
+  // evaluations one iteration can take.  The fixed-step form initialises its interval as converged only while step_size > epsilon / 2; at or
+  // below that (a nonsensical but legal parameter set: the soak drew step_size 0.05 with epsilon 0.1) it runs the trial loop like More-Thuente,
+  // and a budget of one evaluation per iteration cut such pairs off unfinished
+  const bool fixed_one = h->prm.ndt_line_search == DGS_NDT_LS_FIXED_STEP && h->prm.ndt_step_size - h->prm.transformation_epsilon / 2 > 0;
+  const int per_iter = fixed_one ? 1 : (h->prm.ndt_mt_max_step_iterations + 2);
   // (upstream order with speculated Newton steps: an evaluation whose header the exact step refuses is made again -- at most twice the launches)
   const long max_evals = ((long)(h->prm.maximum_iterations + 3) * per_iter + 2) * ((h->consts.strict_order == DGS_NDT_ORDER_UPSTREAM && h->ndt_speculate) ? 2 : 1);
   const int chunk = 4;  // (derivatives, solve) launches between two looks at the done counter

@@ -108,12 +108,14 @@ def main():
             r.setInputTarget(tgt)
             out[order] = r.align_batch(sources, guesses)
         diffs = []
+        ev_only = []
         for c, (x, y) in enumerate(zip(out[1], out[2])):
             tot += 1
             if not np.array_equal(x["T"], y["T"]) or x["iterations"] != y["iterations"] or x["converged"] != y["converged"]:
                 diffs.append((c, int(x["iterations"]), int(y["iterations"]), bool(x["converged"]), bool(y["converged"]), float(np.abs(x["T"] - y["T"]).max())))
             elif x["evaluations"] != y["evaluations"]:
                 ev_diff += 1
+                ev_only.append((c, int(x["evaluations"]), int(y["evaluations"])))
         if diffs and a.oracle_on_difference:   # which of the two runs is the CPU's?  (the history of the process matters: the batches before this one ran too)
             from oracle import oracle as orc
             o = orc.NdtOracle(resolution=res, search_method=search, line_search=kw.get("ndt_line_search", 1), max_iterations=kw.get("maximum_iterations", 64),
@@ -128,7 +130,7 @@ def main():
                                   "order 2": [int(out[2][c]["iterations"]), int(out[2][c]["evaluations"]), bool(np.array_equal(out[2][c]["T"], ro["T"]))]}), flush=True)
         bad += len(diffs)
         print(json.dumps({"batch": b, "kind": kind, "resolution": res, "search": search, "pairs": len(sources), "points": int(len(sources[0])),
-                          "iterations": [int(x["iterations"]) for x in out[2]], "params": {k: v for k, v in kw.items() if k not in ("ndt_resolution", "ndt_search_method")}, "differ": diffs}), flush=True)
+                          "iterations": [int(x["iterations"]) for x in out[2]], "params": {k: v for k, v in kw.items() if k not in ("ndt_resolution", "ndt_search_method")}, "differ": diffs, "other_evaluation_count_only (pair, order 1, order 2)": ev_only}), flush=True)
     print(json.dumps({"pairs": tot, "pairs_that_differ": bad, "pairs_with_other_evaluation_count_only": ev_diff}))
 
 

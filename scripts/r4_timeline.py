@@ -16,4 +16,14 @@ for name, s, e in seq:
         tag = 'S3' if 'strict3' in name else ('H' if 'Lb1ELb1E' in name and 'strict' in name else 'F')
         out.append("%s%.0f" % (tag, (e - s) / 1e3))
 print(" ".join(out))
+it = [(n_, s_, e_) for n_, s_, e_ in seq if 'ndt_strict' in n_ or 'ndt_derivatives' in n_]
+gaps = [(it[k + 1][1] - it[k][2]) / 1e3 for k in range(len(it) - 1)]
+print("gaps_us between consecutive iteration launches:", " ".join("%.1f" % g for g in gaps))
+print("gap sum %.0f us, median %.1f us" % (sum(gaps), sorted(gaps)[len(gaps) // 2]))
+others = {}
+for n_, s_, e_ in seq:
+    if not ('ndt_strict' in n_ or 'ndt_derivatives' in n_):
+        k_ = n_.split('(')[0][-40:]
+        others[k_] = others.get(k_, 0) + (e_ - s_) / 1e3
+print("other kernels in the step (us):", {k_: round(v_, 1) for k_, v_ in sorted(others.items(), key=lambda x: -x[1])[:8]})
 print("launches", len(out), "sum_us %.0f" % sum(float(x.lstrip('SFH3')) if not x.startswith('S3') else float(x[2:]) for x in out), "span_us %.0f" % ((seq[-1][2] - t0) / 1e3))
