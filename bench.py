@@ -243,9 +243,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         mine = torch.tensor([1e3 * dt_own / args.steps, ex_us_own], dtype=torch.float64, device=t.device)
-        allr = torch.empty((world, 2), dtype=torch.float64, device=t.device)
+        allr = torch.empty(world * 2, dtype=torch.float64, device=t.device)   # flat: gloo (the CPU rehearsal) chunks the output and wants chunks of the input's shape
         dist.all_gather_into_tensor(allr, mine)
-        per_rank = allr.cpu().numpy()
+        per_rank = allr.cpu().numpy().reshape(world, 2)
     regs = n_dev * P * args.steps
     value = regs / dt
     records = det.last_records
@@ -255,7 +255,7 @@ def main():
     other_line = None
     if not args.group:
         reg_o = Registration("NDT_OMP", device=local_rank, **dict(reg_kw, ndt_strict_order=other))
-        det_o = LoopDetector({"fitness_score_thresh": 1e9}, registration=reg_o)
+        det_o = LoopDetector({"fitness_score_thresh": 1e9}, registration=reg_o, local_only=True)
         for _ in range(min(args.warmup, 3)):
             det_o.matching(cands, new_kf)
         torch.cuda.synchronize()
@@ -308,7 +308,7 @@ def main():
         os.environ["DGS_NDT_FUSED"] = "0"
         reg_u = Registration("NDT_OMP", device=local_rank, **timed_kw)
         del os.environ["DGS_NDT_FUSED"]
-        det_u = LoopDetector({"fitness_score_thresh": 1e9}, registration=reg_u)
+        det_u = LoopDetector({"fitness_score_thresh": 1e9}, registration=reg_u, local_only=True)
         det_u.matching(cands, new_kf)
         reg_u.profile_enable(True)
         reg_u.profile_reset()
@@ -540,7 +540,7 @@ def parity_legs(args, cpu, records, value, cands, new_kf, tgt, sources, reg_kw, 
     # the order that also sums in point-index order (bit-identical evaluations): one step, for the record
     for mode, reps in ((2, 1),) + (((1, 3),) if 1 not in rec_by_mode else ()):
         rs = Registration("NDT_OMP", device=device, ndt_strict_order=mode, **reg_kw)
-        ds = LoopDetector({"fitness_score_thresh": 1e9}, registration=rs)
+        ds = LoopDetector({"fitness_score_thresh": 1e9}, registration=rs, local_only=True)   # rank 0 alone runs this leg: no collective may be inside
         ds.matching(cands, new_kf)
         torch.cuda.synchronize()
         ts0 = time.perf_counter()

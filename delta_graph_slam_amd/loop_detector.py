@@ -62,7 +62,7 @@ class Loop:
 
 class LoopDetector:
     def __init__(self, params: Optional[dict] = None, registration=None, group=None, device: Optional[int] = None,
-                 cache_clouds: bool = False, filter_on_device: bool = False, cache_capacity: Optional[int] = None):
+                 cache_clouds: bool = False, filter_on_device: bool = False, cache_capacity: Optional[int] = None, local_only: bool = False):
         pr = dict(params or {})
         self.distance_thresh = float(pr.get("distance_thresh", 5.0))
         self.accum_distance_thresh = float(pr.get("accum_distance_thresh", 8.0))
@@ -75,6 +75,9 @@ class LoopDetector:
         self.registration = registration
         self.last_edge_accum_distance = 0.0
         self.group = group
+        # True: this detector registers every candidate it is given on its own device and never enters a collective, whatever process group
+        # exists (side measurements of one rank of a multi-rank job: bench.py's other-order / parity legs)
+        self.local_only = bool(local_only)
         self.last_records = None
         # keyframe id -> DeviceCloud: a keyframe that is a candidate tick after tick (delta_graph_slam_nodelet.cpp:816 calls
         # detect() every graph_update_interval) is uploaded and indexed once; needs KeyFrame.id to be unique
@@ -173,7 +176,7 @@ class LoopDetector:
 
     # ---------------------------------------------------------------------------------------------- sharding
     def _world(self):
-        if dist is not None and dist.is_available() and dist.is_initialized():
+        if not self.local_only and dist is not None and dist.is_available() and dist.is_initialized():
             return dist.get_rank(self.group), dist.get_world_size(self.group)
         return 0, 1
 
