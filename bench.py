@@ -574,7 +574,7 @@ def parity_legs(args, cpu, records, value, cands, new_kf, tgt, sources, reg_kw, 
         "pairs_outside_all_inside_oracle_band": bool(all(o["inside_oracle_band"] for o in outside)),
         "same_best_candidate_as_sequential_reference": bool(b_gpu == b_ref), "best_candidate": int(b_gpu), "reference_best_candidate": int(b_ref),
         "best_fitness_relative_difference": float(abs(s_gpu - s_ref) / s_ref) if b_ref >= 0 and s_ref > 0 else None,
-        "oracle": "CPU restatement of ndt_omp with Eigen's two-sided JacobiSVD sequence, PCL's double computeHessian and the polar-factor guess "
+        "oracle": "CPU restatement of ndt_omp with Eigen's two-sided JacobiSVD and SelfAdjointEigenSolver sequences, PCL's double computeHessian, the polar-factor guess and glibc's expf / exp (those two verified against the image's libm) "
                   "(oracle/cpu; parity unpinned: the reference holds no fixtures, DESIGN.md 2)",
     }
     if args.order == 1 and 0 in rec_by_mode:
