@@ -47,6 +47,12 @@ def _worker(rank, world, port, out_dir):
     loop = det.matching(cands, new)
     np.save(os.path.join(out_dir, f"rec{rank}.npy"), det.last_records)
     np.save(os.path.join(out_dir, f"best{rank}.npy"), np.array([-1 if loop is None else loop.key2.id]))
+    if rank == 0:
+        # a side measurement ONE rank makes while a process group exists (bench.py's parity legs): local_only keeps it out of every collective --
+        # without it this call waits for rank 1's all_gather for ever (found by a two-rank rehearsal of bench.py)
+        side = LoopDetector({"fitness_score_thresh": 10.0}, registration=OracleEngine("NDT_OMP", resolution=2.0, num_threads=2), local_only=True)
+        side.matching(cands, new)
+        np.save(os.path.join(out_dir, "side0.npy"), side.last_records)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,3 +75,4 @@ def test_sharded_matching_equals_sequential(tmp_path):
     assert (-1 if loop is None else loop.key2.id) == bests[0]
     assert recs[0][5, 3] == 4 and recs[0][5, 1] == 0                             # the empty candidate reported DGS_ERR_NO_SOURCE
     assert list(recs[0][:, 0]) == [0, 1, 2, 3, 4, 5]
+    assert np.array_equal(np.load(tmp_path / "side0.npy"), det.last_records, equal_nan=True)   # rank 0's local_only detector registered all six itself
