@@ -211,7 +211,7 @@ def test_repeated_trial_point_of_a_clamped_line_search_takes_its_earlier_value(o
     for s in sources:
         o.set_source(s)
         ref.append(o.align(guesses[len(ref)]))
-    for env in ({}, {"DGS_NDT_FIXED_SLICES": 1}):
+    for env in ({}, {"DGS_NDT_FIXED_SLICES": 1}, {"DGS_NDT_FIXED_SLICES": 1, "DGS_NDT_FUSED": 0}, {"DGS_NDT_SPECULATE": 0}):
         with _env(**env):
             r = _reg(ndt_strict_order=1, **kw)
         r.setInputTarget(tgt)
