@@ -39,7 +39,7 @@ class Params(C.Structure):
         ("vgicp_search_method", C.c_int32), ("vgicp_resolution", C.c_double),
         ("ndt_newton_solver", C.c_int32), ("ndt_hessian_recompute_double", C.c_int32), ("ndt_guess_rotation_polar", C.c_int32),
         ("ndt_exp_glibc", C.c_int32),
-        ("ndt_cov_eigensolver", C.c_int32), ("reserved1", C.c_int32),
+        ("ndt_cov_eigensolver", C.c_int32), ("gicp_cov_jacobi_svd", C.c_int32),
     ]
 
 

@@ -272,6 +272,7 @@ int dgs_params_init(dgs_params* p, int32_t method) {
   p->ndt_guess_rotation_polar = 1;
   p->ndt_exp_glibc = 1;
   p->ndt_cov_eigensolver = 1;
+  p->gicp_cov_jacobi_svd = 0;   // see dgs_reg.h: available, not the default
   p->gicp_max_correspondence_distance = 2.5;
   p->gicp_rotation_epsilon = 2e-3;
   p->gicp_lm_init_lambda_factor = 1e-9;

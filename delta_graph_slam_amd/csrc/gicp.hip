@@ -29,7 +29,9 @@
 namespace dgs {
 
 // ================================================================================================ K4 covariances
-__device__ void regularize_cov(const double* cov9, int method, double* out6) {
+__device__ void regularize_cov(const double* cov9, int method_and_flag, double* out6) {
+  const bool jacobi_svd = (method_and_flag & 0x100) != 0;   // dgs_params.gicp_cov_jacobi_svd rides on the method word
+  const int method = method_and_flag & 0xff;
   double C[9];
   if (method == DGS_GICP_REG_NONE) {
     for (int a = 0; a < 9; a++) C[a] = cov9[a];
@@ -44,10 +46,18 @@ __device__ void regularize_cov(const double* cov9, int method, double* out6) {
     for (int a = 0; a < 9; a++) Ai[a] /= nrm;
     inv3_d(Ai, C);
   } else {
-    // JacobiSVD of a symmetric PSD 3x3 == eigen-decomposition, singular values descending
-    double ev[3], V[9];
-    sym_eig3_d(cov9, ev, V);
-    const double sv[3] = {fabs(ev[2]), fabs(ev[1]), fabs(ev[0])};
+    // Eigen::JacobiSVD<Matrix3d> svd(cov, ComputeFullU | ComputeFullV); cov = U values.asDiagonal() V^T (singular values descending) -- or, rounds
+    // 1-3's stand-in, the eigen-decomposition of the symmetric PSD matrix (the same factors up to rounding, U = V)
+    double U[9], V[9], sv[3];
+    if (jacobi_svd) {
+      jacobi_svd3_d(cov9, U, V, sv);
+    } else {
+      double ev[3], E[9];
+      sym_eig3_d(cov9, ev, E);
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) U[r * 3 + c] = V[r * 3 + c] = E[r * 3 + (2 - c)];   // descending order: column c <- eigenvector 2 - c
+      sv[0] = fabs(ev[2]); sv[1] = fabs(ev[1]); sv[2] = fabs(ev[0]);
+    }
     double vals[3];
     if (method == DGS_GICP_REG_PLANE) {
       vals[0] = 1; vals[1] = 1; vals[2] = 1e-3;
@@ -57,7 +67,7 @@ __device__ void regularize_cov(const double* cov9, int method, double* out6) {
       for (int a = 0; a < 3; a++) vals[a] = fmax(sv[a] / sv[0], 1e-3);
     }
     for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) C[r * 3 + c] = V[r * 3 + 2] * vals[0] * V[c * 3 + 2] + V[r * 3 + 1] * vals[1] * V[c * 3 + 1] + V[r * 3 + 0] * vals[2] * V[c * 3 + 0];
+      for (int c = 0; c < 3; c++) C[r * 3 + c] = U[r * 3 + 0] * vals[0] * V[c * 3 + 0] + U[r * 3 + 1] * vals[1] * V[c * 3 + 1] + U[r * 3 + 2] * vals[2] * V[c * 3 + 2];
   }
   out6[0] = C[0]; out6[1] = C[1]; out6[2] = C[2]; out6[3] = C[4]; out6[4] = C[5]; out6[5] = C[8];
 }
@@ -1133,7 +1143,7 @@ static int ensure_covariance(dgs_handle* h, CloudState& c) {
   }
   constexpr int kCovPerBlock = kCovPerWave * (kBlock / kWave);
   hipLaunchKernelGGL(gicp_cov_from_knn_kernel, dim3((unsigned)(((int64_t)c.n + kCovPerBlock - 1) / kCovPerBlock)), dim3(kBlock), 0, h->stream, v, c.pts.ptr, (int)c.n,
-                     h->gconsts.k, h->gconsts.regularization, h->knn_nbr.ptr, c.cov.ptr);
+                     h->gconsts.k, h->gconsts.regularization | (h->prm.gicp_cov_jacobi_svd ? 0x100 : 0), h->knn_nbr.ptr, c.cov.ptr);
   prof_end(h, DGS_K_GICP_COVARIANCE, slot);
   DGS_HIP_TRY(h, hipGetLastError());
 #ifdef DGS_KNN_STATS

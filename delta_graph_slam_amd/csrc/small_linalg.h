@@ -192,4 +192,122 @@ __device__ inline void eigen_selfadjoint3_d(const double* Ain, double* ev, doubl
   for (int i = 0; i < 9; i++) V[i] = Q[i];
 }
 
+// Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU | ComputeFullV) as Eigen 3.3 executes it for a square real matrix (two-sided Jacobi on A / max|A|, sweeps
+// over (p, q), q < p, real_2x2_jacobi_svd + makeJacobi, signs, descending order): what fast_gicp's calculate_covariances calls on every
+// neighbourhood covariance.  The same sequence of IEEE operations as the CPU checker's generic restatement (the 6 x 6 Newton solve uses it too, laid
+// out across a wave in solve6.h), contraction off.  U, V row-major, sv descending.  dgs_params.gicp_cov_jacobi_svd = 1 (default).
+__device__ inline void jacobi_svd3_d(const double* A, double* U, double* V, double* sv) {
+#pragma clang fp contract(off)
+  constexpr int N = 3;
+  const double precision = 2.0 * 2.220446049250313e-16, consider_as_zero = 2.2250738585072014e-308;
+  double scale = 0.0;
+  for (int i = 0; i < N * N; i++) { const double a = fabs(A[i]); if (a > scale) scale = a; }
+  if (scale == 0.0) scale = 1.0;
+  double W[N * N];
+  for (int i = 0; i < N * N; i++) { W[i] = A[i] / scale; U[i] = V[i] = (i % (N + 1) == 0) ? 1.0 : 0.0; }
+  double max_diag = 0.0;
+  for (int i = 0; i < N; i++) { const double a = fabs(W[i * (N + 1)]); if (a > max_diag) max_diag = a; }
+  int sweeps = 0;
+  bool finished = false;
+  while (!finished && sweeps < 64) {
+    finished = true;
+    sweeps++;
+#pragma unroll
+    for (int p = 1; p < N; p++)
+#pragma unroll
+      for (int q = 0; q < p; q++) {
+        const double pm = precision * max_diag;
+        const double threshold = consider_as_zero > pm ? consider_as_zero : pm;
+        if (!(fabs(W[p * N + q]) > threshold || fabs(W[q * N + p]) > threshold)) continue;
+        finished = false;
+        double m00 = W[p * N + p], m01 = W[p * N + q], m10 = W[q * N + p], m11 = W[q * N + q];
+        const double t = m00 + m11, d = m10 - m01;
+        double r1c, r1s;
+        if (fabs(d) < consider_as_zero) { r1s = 0.0; r1c = 1.0; }
+        else {
+          const double u = t / d;
+          const double tmp = sqrt(1.0 + u * u);
+          r1s = 1.0 / tmp;
+          r1c = u / tmp;
+        }
+        if (!(r1c == 1.0 && r1s == 0.0)) {
+          const double x0 = m00, y0 = m10, x1 = m01, y1 = m11;
+          m00 = r1c * x0 + r1s * y0; m10 = -r1s * x0 + r1c * y0;
+          m01 = r1c * x1 + r1s * y1; m11 = -r1s * x1 + r1c * y1;
+        }
+        double jrc, jrs;
+        {
+          const double deno = 2.0 * fabs(m01);
+          if (deno < consider_as_zero) { jrc = 1.0; jrs = 0.0; }
+          else {
+            const double tau = (m00 - m11) / deno;
+            const double w = sqrt(tau * tau + 1.0);
+            const double tt = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+            const double sign_t = tt > 0.0 ? 1.0 : -1.0;
+            const double nn = 1.0 / sqrt(tt * tt + 1.0);
+            jrs = -sign_t * (m01 / fabs(m01)) * fabs(tt) * nn;
+            jrc = nn;
+          }
+        }
+        const double jtc = jrc, jts = -jrs;
+        const double jlc = r1c * jtc - r1s * jts;
+        const double jls = r1c * jts + r1s * jtc;
+        if (!(jlc == 1.0 && jls == 0.0)) {
+#pragma unroll
+          for (int i = 0; i < N; i++) {
+            const double xi = W[p * N + i], yi = W[q * N + i];
+            W[p * N + i] = jlc * xi + jls * yi;
+            W[q * N + i] = -jls * xi + jlc * yi;
+          }
+#pragma unroll
+          for (int i = 0; i < N; i++) {
+            const double xi = U[i * N + p], yi = U[i * N + q];
+            U[i * N + p] = jlc * xi + jls * yi;
+            U[i * N + q] = -jls * xi + jlc * yi;
+          }
+        }
+        if (!(jrc == 1.0 && -jrs == 0.0)) {
+          const double c = jrc, s = -jrs;
+#pragma unroll
+          for (int i = 0; i < N; i++) {
+            const double xi = W[i * N + p], yi = W[i * N + q];
+            W[i * N + p] = c * xi + s * yi;
+            W[i * N + q] = -s * xi + c * yi;
+          }
+#pragma unroll
+          for (int i = 0; i < N; i++) {
+            const double xi = V[i * N + p], yi = V[i * N + q];
+            V[i * N + p] = c * xi + s * yi;
+            V[i * N + q] = -s * xi + c * yi;
+          }
+        }
+        const double app = fabs(W[p * N + p]), aqq = fabs(W[q * N + q]);
+        const double mx = app < aqq ? aqq : app;
+        if (max_diag < mx) max_diag = mx;
+      }
+  }
+  for (int i = 0; i < N; i++) {
+    const double a = W[i * (N + 1)];
+    sv[i] = fabs(a);
+    if (a < 0.0)
+      for (int k = 0; k < N; k++) U[k * N + i] = -U[k * N + i];
+  }
+  for (int i = 0; i < N; i++) sv[i] *= scale;
+  for (int i = 0; i < N; i++) {
+    int pos = 0;
+    double best = sv[i];
+    for (int k = 1; k < N - i; k++)
+      if (sv[i + k] > best) { best = sv[i + k]; pos = k; }
+    if (best == 0.0) break;
+    if (pos) {
+      pos += i;
+      { const double t = sv[i]; sv[i] = sv[pos]; sv[pos] = t; }
+      for (int k = 0; k < N; k++) {
+        { const double t = U[k * N + i]; U[k * N + i] = U[k * N + pos]; U[k * N + pos] = t; }
+        { const double t = V[k * N + i]; V[k * N + i] = V[k * N + pos]; V[k * N + pos] = t; }
+      }
+    }
+  }
+}
+
 }  // namespace dgs

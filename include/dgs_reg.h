@@ -119,7 +119,7 @@ typedef struct dgs_params {
   /* FAST_VGICP (uses the gicp_* fields above except gicp_max_correspondence_distance: VGICP has no distance gate) */
   int32_t vgicp_search_method;             /* default DGS_VGICP_DIRECT1 (FastVGICP constructor) */
   double vgicp_resolution;                 /* setResolution(reg_resolution), factory default 1.0 (registrations.cpp:52) */
-  /* ---- five details of un-vendored upstream code behind named switches (ABI 5; [UPSTREAM-RECALL]).  Each
+  /* ---- six details of un-vendored upstream code behind named switches (ABI 5; [UPSTREAM-RECALL]).  Each
    * defaults to what the published upstream source does as far as it can be recalled; 0 restores the stand-in of ABI <= 4. ---- */
   int32_t ndt_newton_solver;            /* upstream evaluation orders (ndt_strict_order >= 1): 1 = Eigen::JacobiSVD's own two-sided Jacobi sequence
                                            (what computeTransformation's `sv.solve(-score_gradient)` runs); 0 = one-sided Hestenes Jacobi.  The FAST
@@ -138,7 +138,11 @@ typedef struct dgs_params {
                                            SelfAdjointEigenSolver<Matrix3d>::compute restated -- scaling, the 3x3 Householder tridiagonalisation,
                                            implicit QR steps with Wilkinson's shift, selection sort; 0 = cyclic Jacobi (ABI <= 4).  The eigenvectors
                                            matter where a flat voxel's covariance is rebuilt from them (eigenvalue clamp). */
-  int32_t reserved1;
+  int32_t gicp_cov_jacobi_svd;          /* FAST_GICP / FAST_VGICP covariance regularisation (calculate_covariances): 1 = Eigen::JacobiSVD<Matrix3d> restated (two-sided
+                                           Jacobi; the routine fast_gicp calls), 0 (default) = the symmetric eigen-decomposition of ABI <= 4 -- the same factors up to
+                                           rounding on regular neighbourhoods.  Not the default because JacobiSVD skips rotations below 2 eps maxDiag: on a rank-deficient
+                                           neighbourhood (duplicated points, points on a line) the basis of the null space -- and with it U diag(1, 1, 1e-3) V^T -- then
+                                           jumps with the last bit of the input covariance, which the device and a CPU sum in different orders.  (Was reserved1.) */
 } dgs_params;
 
 /* What the callers read back after align(): hasConverged(), getFinalTransformation(), and the

@@ -107,11 +107,18 @@ void GicpCpu::calc_covariances(const std::vector<float>& cloud, int64_t n, const
       for (int a = 0; a < 9; a++) Ci[a] /= nrm;
       inv3(Ci, out);
     } else {
-      // JacobiSVD of a symmetric PSD 3x3 == eigen-decomposition; singular values descending
-      double ev[3], V[9];
-      sym_eig3(cov, ev, V);
-      const double sv[3] = {std::fabs(ev[2]), std::fabs(ev[1]), std::fabs(ev[0])};
-      const int col[3] = {2, 1, 0};
+      // Eigen::JacobiSVD<Matrix3d> svd(cov, ComputeFullU | ComputeFullV); cov = U * values.asDiagonal() * V^T   (singular values descending)
+      double U[9], V[9], sv[3];
+      int col[3] = {0, 1, 2};
+      if (prm.cov_svd) {
+        jacobi_svd_square<double, 3>(cov, U, V, sv);
+      } else {   // rounds 1-3: the eigen-decomposition of the symmetric PSD matrix (same factors up to rounding, U = V)
+        double ev[3];
+        sym_eig3(cov, ev, V);
+        std::memcpy(U, V, sizeof(U));
+        sv[0] = std::fabs(ev[2]); sv[1] = std::fabs(ev[1]); sv[2] = std::fabs(ev[0]);
+        col[0] = 2; col[1] = 1; col[2] = 0;
+      }
       double vals[3];
       if (prm.regularization == GICP_REG_PLANE) {
         vals[0] = 1; vals[1] = 1; vals[2] = 1e-3;
@@ -123,7 +130,7 @@ void GicpCpu::calc_covariances(const std::vector<float>& cloud, int64_t n, const
       for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) {
           double s = 0;
-          for (int a = 0; a < 3; a++) s += V[r * 3 + col[a]] * vals[a] * V[c * 3 + col[a]];
+          for (int a = 0; a < 3; a++) s += U[r * 3 + col[a]] * vals[a] * V[c * 3 + col[a]];
           out[r * 3 + c] = s;
         }
     }

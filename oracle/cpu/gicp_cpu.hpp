@@ -29,6 +29,9 @@ struct GicpParams {
   int optimizer = GICP_OPT_LM;
   int lm_max_iterations = 10;
   int num_threads = 0;
+  int cov_svd = 0;   // covariance regularisation: 1 = Eigen::JacobiSVD<Matrix3d> restated (two-sided Jacobi, linalg.hpp jacobi_svd_square<double, 3>), what
+                     // fast_gicp's calculate_covariances calls; 0 (default) = symmetric eigen-decomposition: the same factors up to rounding on regular
+                     // neighbourhoods; on rank-deficient ones JacobiSVD's rotation threshold makes the result jump with the last bit of the input
 };
 
 struct GicpResult {

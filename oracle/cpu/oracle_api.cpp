@@ -213,6 +213,8 @@ void orc_gicp_default_params(orc_gicp_params* p) {
   p->optimizer = d.optimizer;
   p->lm_max_iterations = d.lm_max_iterations;
   p->num_threads = d.num_threads;
+  p->cov_svd = d.cov_svd;
+  p->pad0 = 0;
 }
 void* orc_gicp_create(const orc_gicp_params* p) {
   GicpParams d;
@@ -226,6 +228,7 @@ void* orc_gicp_create(const orc_gicp_params* p) {
   d.optimizer = p->optimizer;
   d.lm_max_iterations = p->lm_max_iterations;
   d.num_threads = p->num_threads;
+  d.cov_svd = p->cov_svd;
   return new GicpCpu(d);
 }
 static GicpParams gicp_params_from(const orc_gicp_params* p) {
@@ -240,6 +243,7 @@ static GicpParams gicp_params_from(const orc_gicp_params* p) {
   d.optimizer = p->optimizer;
   d.lm_max_iterations = p->lm_max_iterations;
   d.num_threads = p->num_threads;
+  d.cov_svd = p->cov_svd;
   return d;
 }
 /* FAST_VGICP: the returned object is used through the orc_gicp_* entry points */

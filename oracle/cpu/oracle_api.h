@@ -50,6 +50,7 @@ int32_t orc_max_threads(void);
 typedef struct orc_gicp_params {
   double transformation_epsilon, rotation_epsilon, max_correspondence_distance, lm_init_lambda_factor;
   int32_t max_iterations, k_correspondences, regularization, optimizer, lm_max_iterations, num_threads;
+  int32_t cov_svd, pad0;
 } orc_gicp_params;
 void orc_gicp_default_params(orc_gicp_params* p);
 void* orc_gicp_create(const orc_gicp_params* p);

@@ -47,7 +47,7 @@ class GicpParams(C.Structure):
     _fields_ = [("transformation_epsilon", C.c_double), ("rotation_epsilon", C.c_double),
                 ("max_correspondence_distance", C.c_double), ("lm_init_lambda_factor", C.c_double),
                 ("max_iterations", C.c_int32), ("k_correspondences", C.c_int32), ("regularization", C.c_int32),
-                ("optimizer", C.c_int32), ("lm_max_iterations", C.c_int32), ("num_threads", C.c_int32)]
+                ("optimizer", C.c_int32), ("lm_max_iterations", C.c_int32), ("num_threads", C.c_int32), ("cov_svd", C.c_int32), ("pad0", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -327,7 +327,7 @@ class GicpOracle:
 
     def __init__(self, transformation_epsilon=0.01, max_iterations=64, max_correspondence_distance=2.5, k_correspondences=20,
                  rotation_epsilon=2e-3, regularization="PLANE", optimizer=1, lm_max_iterations=10, lm_init_lambda_factor=1e-9,
-                 num_threads=0, perturbed=False):
+                 num_threads=0, perturbed=False, cov_svd=0):
         L = lib(perturbed)
         self._L = L
         p = GicpParams()
@@ -342,6 +342,7 @@ class GicpOracle:
         p.lm_max_iterations = lm_max_iterations
         p.lm_init_lambda_factor = lm_init_lambda_factor
         p.num_threads = num_threads
+        p.cov_svd = cov_svd   # covariance regularisation through Eigen's JacobiSVD restated (1) / the symmetric eigen-decomposition (0)
         self.params = p
         self._h = self._create(L, p)
         self.ns = self.nt = 0

@@ -70,7 +70,7 @@ def test_defaults_are_the_reference_factory_defaults():
         assert p.vgicp_resolution == 1.0 and p.vgicp_search_method == L.VGICP_SEARCH["DIRECT1"]      # registrations.cpp:52, FastVGICP ctor
         # the evaluation order that reproduces a CPU run of upstream is the default (ABI 5); the re-associated fast order is opt-in
         assert p.ndt_strict_order == 1 and p.ndt_newton_solver == 1 and p.ndt_hessian_recompute_double == 1 and p.ndt_guess_rotation_polar == 1
-        assert p.ndt_exp_glibc == 1 and p.ndt_cov_eigensolver == 1 and p.reserved1 == 0
+        assert p.ndt_exp_glibc == 1 and p.ndt_cov_eigensolver == 1 and p.gicp_cov_jacobi_svd == 0
     assert lib.dgs_params_init(C.byref(L.Params()), 7) == 1      # unknown method: DGS_ERR_INVALID_ARGUMENT
     assert lib.dgs_params_init(None, 0) == 1
 

@@ -263,3 +263,41 @@ def test_fused_rounds_equal_separate_solve_launches_bit_for_bit(method):
         assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["evaluations"] == b["evaluations"]
         assert a["converged"] == b["converged"] and a["fitness"] == b["fitness"]
     assert np.array_equal(out["1"][1], out["0"][1]) and out["1"][2] == out["0"][2]
+
+
+@pytest.mark.parametrize("method", ["FAST_GICP", "FAST_VGICP"])
+def test_covariance_regularisation_through_the_jacobi_svd_switch(oracle_lib, method):
+    """dgs_params.gicp_cov_jacobi_svd = 1 / GicpParams::cov_svd = 1: fast_gicp's `JacobiSVD<Matrix3d> svd(cov); cov = U diag V^T` restated (two-sided
+    Jacobi, the same generic routine as the Newton solve) instead of the symmetric eigen-decomposition.  On a regular scene both give the same
+    covariances to rounding, the device equals the oracle under either switch (sums to 1e-9, pose inside the gate), and the switch changes the
+    oracle's answer by less than the gate.  It is NOT the default: on rank-deficient neighbourhoods (the fuzz sweep's duplicated points)
+    JacobiSVD's rotation threshold makes the regularised covariance jump with the last bit of its input (include/dgs_reg.h)."""
+    from delta_graph_slam_amd import _lib as L
+    from delta_graph_slam_amd.registration import Registration
+    from tests.helpers import TOL_ROT, TOL_TRANS, pose_error
+    tgt, src, Tgt = synth.kitti_pair(n_points=16384)
+    guess = Tgt.copy().astype(np.float32)
+    guess[0, 3] -= 0.2
+    runs = {}
+    for svd in (0, 1):
+        if method == "FAST_GICP":
+            o = oracle_lib.GicpOracle(max_correspondence_distance=2.0, cov_svd=svd)
+            r = Registration(method, gicp_max_correspondence_distance=2.0, gicp_cov_jacobi_svd=svd)
+        else:
+            o = oracle_lib.VgicpOracle(resolution=1.0, cov_svd=svd)
+            r = Registration(method, vgicp_resolution=1.0, gicp_cov_jacobi_svd=svd)
+        o.set_target(tgt)
+        o.set_source(src)
+        r.setInputTarget(tgt)
+        r.setInputSource(src)
+        eo, Ho, bo = o.linearize(guess.astype(np.float64))
+        eg, Hg, bg = r.gicp_linearize(guess.astype(np.float64))
+        assert abs(eo - eg) <= 1e-9 * abs(eo) and np.abs(Ho - Hg).max() <= 1e-9 * np.abs(Ho).max(), (svd, abs(eo - eg) / abs(eo))
+        ro = o.align(guess)
+        r.align(guess)
+        dt, dr = pose_error(r.getFinalTransformation(), ro["T"])
+        assert r.hasConverged() == ro["converged"] and dt <= TOL_TRANS and dr <= TOL_ROT, (svd, dt, dr)
+        runs[svd] = (eo, ro["T"])
+    assert abs(runs[0][0] - runs[1][0]) <= 1e-9 * abs(runs[0][0])
+    dt, dr = pose_error(runs[0][1], runs[1][1])
+    assert dt <= TOL_TRANS and dr <= TOL_ROT
